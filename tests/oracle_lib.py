@@ -1,0 +1,107 @@
+"""ctypes view of oracle/libffv2_oracle.so -- TEST-SIDE ONLY (never imported by
+the ffmpeg_ffv2_amd package)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "libffv2_oracle.so")
+
+PIX = {"gray": 8, "yuv444p": 5, "yuv444p10le": 70, "yuv444p12le": 133,
+       "gbrp": 73, "gbrp10le": 77, "gbrp12le": 137}
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.ffv2o_encode_frame.restype = C.c_int
+        lib.ffv2o_tstage.restype = C.c_int
+        lib.ffv2o_coded_gain.restype = C.c_uint32
+        lib.ffv2o_coded_gain.argtypes = [C.c_int64]
+        lib.ffv2o_golomb.restype = C.c_int
+        lib.ffv2o_pvq_search.restype = C.c_float
+
+    @staticmethod
+    def _planes(frame):
+        """frame: (P,H,W) uint8 or uint16 array -> data[4], linesize[4]"""
+        frame = np.ascontiguousarray(frame)
+        P = frame.shape[0]
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(P):
+            data[p] = frame[p].ctypes.data
+            ls[p] = frame[p].strides[0]
+        return frame, data, ls
+
+    def encode(self, frame, pix_fmt, qp=0, W=None):
+        frame, data, ls = self._planes(frame)
+        P, H, Wd = frame.shape
+        cap = 64 + 64 * frame.size
+        out = np.zeros(cap, np.uint8)
+        size = C.c_size_t(0)
+        wp = None
+        if W is not None:
+            W = np.ascontiguousarray(W, np.int32)
+            wp = W.ctypes.data_as(C.c_void_p)
+        r = self.lib.ffv2o_encode_frame(data, ls, C.c_int(Wd), C.c_int(H), C.c_int(PIX[pix_fmt]),
+                                        C.c_int(qp), wp, out.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(cap), C.byref(size))
+        if r < 0:
+            raise RuntimeError("oracle error %d" % r)
+        return out[:size.value].tobytes()
+
+    def tstage(self, frame, pix_fmt):
+        frame, data, ls = self._planes(frame)
+        P, H, Wd = frame.shape
+        nsb = ((Wd + 63) // 64) * ((H + 63) // 64)
+        coef = np.zeros((nsb * P, 4096), np.int32)
+        en = np.zeros((nsb * P, 13), np.int64)
+        r = self.lib.ffv2o_tstage(data, ls, C.c_int(Wd), C.c_int(H), C.c_int(PIX[pix_fmt]),
+                                  coef.ctypes.data_as(C.c_void_p), en.ctypes.data_as(C.c_void_p))
+        if r < 0:
+            raise RuntimeError("oracle error %d" % r)
+        return coef, en
+
+    def fdct64(self, x):
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.zeros_like(x)
+        for i in range(x.shape[0]):
+            self.lib.ffv2o_fdct64(y[i].ctypes.data_as(C.c_void_p), x[i].ctypes.data_as(C.c_void_p), C.c_int(1))
+        return y
+
+    def lap32(self, x):
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.zeros_like(x)
+        for i in range(x.shape[0]):
+            self.lib.ffv2o_lap_filter32(y[i].ctypes.data_as(C.c_void_p), x[i].ctypes.data_as(C.c_void_p))
+        return y
+
+    def coded_gain(self, igain):
+        return int(self.lib.ffv2o_coded_gain(int(igain)))
+
+    def golomb(self, val):
+        pat = C.c_uint64(0)
+        n = self.lib.ffv2o_golomb(C.c_uint32(val), C.byref(pat))
+        return n, pat.value
+
+    def pvq_search(self, X, K):
+        X = np.ascontiguousarray(X, np.float32)
+        N = X.shape[0]
+        Xp = np.zeros(N + 8, np.float32)
+        Xp[:N] = X
+        y = np.zeros(N + 8, np.int32)
+        self.lib.ffv2o_pvq_search(Xp.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                  C.c_int(K), C.c_int(N))
+        return y[:N].copy()
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
+def load():
+    if not os.path.exists(SO):
+        build()
+    return Oracle(C.CDLL(SO))

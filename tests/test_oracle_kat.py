@@ -1,0 +1,104 @@
+"""Pins the CPU oracle (oracle/) against the reference's known answers.
+
+Sources of truth:
+  * SURVEY.md section 8 "Known-answer vectors": packets produced by the compiled
+    reference encoder (clang-built: phantom coefficient W = 0; gcc-built rows
+    give the W != 0 cases) at qp = 0, captured by the survey in this container.
+  * tests/golden/fdct64_vectors.npz: the reference's own od_bin_fdct64 statement
+    text executed numerically (tools/derive_lifting_ir.py), 355 vectors.
+CPU only.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def test_kat_gray64_flat(oracle):
+    assert oracle.encode(np.full((1, 64, 64), 128, np.uint8), "gray").hex() == "007ffe18"
+    # proves the 4x4 scan quirk (true DC at coding index 15) and the DC gain of 64
+    assert oracle.encode(np.full((1, 64, 64), 255, np.uint8), "gray").hex() == "001fffa8002218"
+
+
+def test_kat_gray64_phantom_w(oracle):
+    # gcc-built reference, ASLR off: band-12 coded gain 4  <=>  |W| in 8..11
+    for w in (8, 9, 10, 11, -8, -11):
+        assert oracle.encode(np.full((1, 64, 64), 128, np.uint8), "gray", W=[w]).hex() == "00063ffe18"
+    assert oracle.encode(np.full((1, 64, 64), 128, np.uint8), "gray", W=[7]).hex() != "00063ffe18"
+
+
+def test_kat_noise_yuv444p_320x240(oracle):
+    fr = np.random.default_rng(1234).integers(0, 256, (5, 3, 240, 320), dtype=np.uint8)
+    assert md5(fr.tobytes()) == "e5f5cb6f17b0bb955c4c983a22e4742b"
+    pk = b"".join(oracle.encode(fr[i], "yuv444p") for i in range(5))
+    assert len(pk) == 9565
+    assert md5(pk) == "08700eaee86fe100fef32f338264c357"
+
+
+def test_kat_noise_yuv444p10_192x128(oracle):
+    fr = np.random.default_rng(99).integers(0, 1024, (2, 3, 128, 192), dtype=np.uint16)
+    assert md5(fr.astype("<u2").tobytes()) == "50ea6c49a4816c700eeff712bc7d7245"
+    pk = b"".join(oracle.encode(fr[i], "yuv444p10le") for i in range(2))
+    assert len(pk) == 1145
+    assert md5(pk) == "fb85644e9fc183e66a576ce8bd11bd6e"
+
+
+def test_kat_ramp_gray_150x100(oracle):
+    y, x = np.mgrid[0:100, 0:150]
+    g = ((3 * x + 5 * y) % 256).astype(np.uint8)[None]
+    assert md5(g.tobytes()) == "f6f7768b487171df0d67e67be28e9744"
+    pk = oracle.encode(g, "gray")
+    assert len(pk) == 192
+    assert md5(pk) == "d3154b32ce9f33ccc860bd195259f3d8"
+
+
+def test_kat_flat_320x256(oracle):
+    grey = np.full((3, 256, 320), 128, np.uint8)
+    white = np.full((3, 256, 320), 255, np.uint8)
+    assert len(oracle.encode(grey, "yuv444p")) == 117        # clang-built reference, W = 0
+    assert len(oracle.encode(white, "yuv444p")) == 282
+    # gcc-built reference, ASLR off: W = superblock row index (0,1,2,3)
+    w = np.repeat(np.arange(4), 5 * 3).astype(np.int32)
+    assert len(oracle.encode(grey, "yuv444p", W=w)) == 128
+    # gcc-built reference, ASLR on: W constant in 3..5
+    for c in (3, 4, 5):
+        assert len(oracle.encode(grey, "yuv444p", W=np.full(60, c))) == 132
+        assert len(oracle.encode(white, "yuv444p", W=np.full(60, c))) == 297
+
+
+def test_fdct64_golden_vectors(oracle):
+    g = np.load(os.path.join(GOLD, "fdct64_vectors.npz"))
+    assert np.array_equal(oracle.fdct64(g["x"]), g["y"])
+
+
+def test_fdct64_is_orthonormal_dct2(oracle):
+    n = 64
+    k = np.arange(n)[:, None]
+    i = np.arange(n)[None, :]
+    Cm = np.sqrt(2.0 / n) * np.cos(np.pi * (2 * i + 1) * k / (2 * n))
+    Cm[0] /= np.sqrt(2.0)
+    x = np.random.default_rng(5).integers(-2048, 2048, (64, 64)).astype(np.int32)
+    assert np.abs(oracle.fdct64(x) - x @ Cm.T).max() < 6.0
+
+
+def test_golomb_lengths(oracle):
+    for v in (0, 1, 2, 3, 6, 7, 2565, 2566, 65534, 65535, 10 ** 6):
+        n, pat = oracle.golomb(v)
+        assert n == 2 * int(np.floor(np.log2(v + 1))) + 1
+        assert (pat >> (n - 1)) == 1                          # terminating 1 is the last bit
+    assert oracle.golomb(0) == (1, 1)
+    assert oracle.golomb(1) == (3, 0b100)                     # v=2: bit 0 -> [0,0], then 1
+    assert oracle.golomb(2) == (3, 0b110)                     # v=3: bit 1 -> [0,1], then 1
+
+
+def test_rejected_pix_fmt(oracle):
+    # yuv420p (0) and friends are not in allowed_pix_fmts (ffv2enc.c:596-601)
+    assert oracle.lib.ffv2o_pixfmt_info(0, None, None) < 0
+    assert oracle.lib.ffv2o_pixfmt_info(5, None, None) == 0

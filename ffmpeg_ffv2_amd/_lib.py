@@ -1,0 +1,68 @@
+"""ctypes binding of libffv2amd.so (include/ffv2_amd.h).  No fallback: if the
+shared library is missing this raises, it never routes to a CPU path."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(PKG, "libffv2amd.so")
+
+EXPORTS = [
+    "ffv2amd_version", "ffv2amd_encoder_create", "ffv2amd_encoder_destroy", "ffv2amd_encoder_info",
+    "ffv2amd_encode_frame", "ffv2amd_encode_batch_device", "ffv2amd_tstage_device",
+    "ffv2amd_coded_gain", "ffv2amd_range_prefix",
+    # AVCodec-shaped host shim (ffv2enc_amd.c)
+    "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
+]
+
+ERRORS = {-22: "EINVAL", -12: "ENOMEM", -5: "EIO (HIP device/runtime)", -28: "ENOSPC",
+          -34: "ERANGE (sample exceeds bit depth / gain table)", -1: "reference would abort",
+          -38: "ENOSYS (not supported)"}
+
+
+class Info(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("pix_fmt", C.c_int),
+                ("planes", C.c_int), ("depth", C.c_int),
+                ("num_sb_x", C.c_int), ("num_sb_y", C.c_int),
+                ("block_planes", C.c_int), ("max_batch", C.c_int),
+                ("packet_cap", C.c_size_t), ("tstage_bytes_per_frame", C.c_size_t),
+                ("row_pitch", C.c_size_t), ("plane_stride", C.c_size_t), ("frame_stride", C.c_size_t)]
+
+
+class FFV2Error(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed: %d %s" % (what, code, ERRORS.get(code, "")))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise RuntimeError("%s is missing: build it with `python -m ffmpeg_ffv2_amd.build` "
+                           "(hipcc, gfx950). There is no CPU fallback." % SO)
+    lib = C.CDLL(SO)
+    lib.ffv2amd_version.restype = C.c_char_p
+    lib.ffv2amd_encoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ffv2amd_encoder_destroy.argtypes = [C.c_void_p]
+    lib.ffv2amd_encoder_destroy.restype = None
+    lib.ffv2amd_encoder_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+    lib.ffv2amd_encode_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.ffv2amd_encode_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ffv2amd_tstage_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ffv2amd_coded_gain.argtypes = [C.c_int64]
+    lib.ffv2amd_coded_gain.restype = C.c_uint32
+    lib.ffv2amd_range_prefix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code < 0:
+        raise FFV2Error(code, what)
+    return code

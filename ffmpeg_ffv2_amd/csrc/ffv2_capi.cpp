@@ -1,0 +1,395 @@
+// ffv2_capi.cpp -- host side of the C-ABI declared in include/ffv2_amd.h.
+// Owns device workspaces and launches the gfx950 kernels; holds the two small
+// pieces of host arithmetic the packet needs:
+//   * the coded-gain threshold table (so that the device never evaluates pow),
+//   * the data-independent range-coded prefix of a qp == 0 packet.
+// There is no CPU encode path in here: without a HIP device every entry point
+// that needs one returns FFV2AMD_ERR_DEVICE.
+#include "../../include/ffv2_amd.h"
+#include "ffv2_kernels.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "gen/scan_lut.h"
+
+#define FFV2AMD_VERSION "ffv2-amd 0.1 (gfx950)"
+
+namespace {
+
+// ------------------------------------------------------------------
+// coded gain (ffv2enc.c:131-138,166,174) and its threshold table
+// ------------------------------------------------------------------
+inline uint32_t coded_gain_host(int64_t e)
+{
+    volatile float fgain = sqrtf((float)e) + FLT_EPSILON;
+    float g = (float)(pow((double)fgain, (double)(1.0f / 1.5f)) / (double)1);
+    return (uint32_t)g;
+}
+
+constexpr int GAIN_TABLE_N = 1 << 15;   // gains 1..32768 <=> energies up to ~3.5e13
+                                        // (Parseval bound of a real block: ~2.4e12)
+std::once_flag g_thr_once;
+std::vector<int64_t> g_thr;             // g_thr[n] = least energy e with coded_gain(e) >= n+1
+
+void build_gain_table()
+{
+    g_thr.resize(GAIN_TABLE_N);
+    int64_t prev = 0;
+    for (int n = 0; n < GAIN_TABLE_N; n++) {
+        const uint32_t t = (uint32_t)n + 1;
+        // coded_gain(e) ~ e^(1/3): bracket around t^3, then bisect (the function is
+        // a monotone staircase in e: int64->float, sqrtf, +eps, pow, casts all are)
+        double c = (double)t * t * t;
+        int64_t hi = (int64_t)(c * 1.001) + 4;
+        while (coded_gain_host(hi) < t) hi = hi * 2 + 1;
+        int64_t lo = (int64_t)(c * 0.999) - 4;
+        if (lo < prev || coded_gain_host(lo) >= t) lo = prev;        // gain(lo) < t or lo is prev
+        if (coded_gain_host(lo) >= t) { g_thr[n] = lo; prev = lo; continue; }
+        while (hi - lo > 1) {                                       // gain(lo) < t <= gain(hi)
+            int64_t mid = lo + (hi - lo) / 2;
+            if (coded_gain_host(mid) >= t) hi = mid; else lo = mid;
+        }
+        g_thr[n] = hi;
+        prev = hi;
+    }
+}
+
+// ------------------------------------------------------------------
+// Daala range encoder, the subset a qp == 0 packet needs
+// (daala_entropy.c:107-151 renormalise, :362-378 interval update,
+//  :399-410 uint, :428-440 adaptive CDF, :624-674 final bits)
+// ------------------------------------------------------------------
+struct RangeEnc {
+    uint64_t low = 0;
+    uint32_t rng = 0x8000;
+    int cnt = -9;
+    std::vector<uint16_t> pre;
+
+    static int ilog(uint32_t v) { return v ? 32 - __builtin_clz(v) : 0; }
+
+    void encode(uint32_t fl, uint32_t fh, uint32_t ft)      // 16384 <= ft <= 32768 <= rng
+    {
+        const int sc = (rng - ft) >= ft;
+        fl <<= sc; fh <<= sc; ft <<= sc;
+        const uint32_t d = rng - ft;
+        const uint32_t g = 2 * d > ft ? 2 * d - ft : 0;
+        auto map = [&](uint32_t x) {
+            const uint32_t a = x < g ? x : g;
+            const uint32_t b = (x > g ? x - g : 0) >> 1;
+            return x + a + (b < d ? b : d);
+        };
+        const uint32_t u = map(fl), v = map(fh);
+        renorm(low + u, v - u);
+    }
+    void renorm(uint64_t l, uint32_t r)
+    {
+        const int d = 16 - ilog(r);
+        int c = cnt, s = c + d;
+        if (s >= 0) {
+            c += 16;
+            uint64_t m = ((uint64_t)1 << c) - 1;
+            if (s >= 8) { pre.push_back((uint16_t)(l >> c)); l &= m; c -= 8; m >>= 8; }
+            pre.push_back((uint16_t)(l >> c));
+            s = c + d - 24;
+            l &= m;
+        }
+        low = l << d; rng = r << d; cnt = s;
+    }
+    // returns the number of unused low bits in the last byte
+    int finish(std::vector<uint8_t> &bytes)
+    {
+        uint64_t m = 0x7FFF, e = (low + m) & ~m;
+        int s = 9, c = cnt;
+        while ((e | m) >= low + rng) { s++; m >>= 1; e = (low + m) & ~m; }
+        s += c;
+        if (s > 0) {
+            uint64_t n = ((uint64_t)1 << (c + 16)) - 1;
+            do { pre.push_back((uint16_t)(e >> (c + 16))); e &= n; s -= 8; c -= 8; n >>= 8; } while (s > 0);
+        }
+        bytes.resize(pre.size());
+        uint32_t carry = 0;
+        for (size_t i = pre.size(); i-- > 0;) { carry += pre[i]; bytes[i] = (uint8_t)carry; carry >>= 8; }
+        return -s;
+    }
+};
+
+int range_prefix(int pix_fmt, int num_sb, std::vector<uint8_t> &bytes, int *slack)
+{
+    if (pix_fmt < 0 || pix_fmt >= 196 || num_sb < 1) return FFV2AMD_ERR_INVAL;
+    RangeEnc rc;
+    // ff_daalaent_encode_uint(pix_fmt, 196): 13-ary uniform Q15 symbol pix_fmt>>4
+    // (daalatab.c row 13: round(32768*k/13)), the low 4 bits travel as raw bits.
+    const uint32_t s = (uint32_t)pix_fmt >> 4;
+    auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
+    rc.encode(s ? q15(s) : 0, q15(s + 1), 32768);
+    // one adaptive 4-ary symbol "no split" per superblock (ffv2enc.c:222; CDF init
+    // {32,64,96,128}, +128 from the coded symbol on, halved past 32767:
+    // daala_entropy.h:140-161, daala_entropy.c:434-439)
+    uint32_t cdf[4] = { 32, 64, 96, 128 };
+    for (int i = 0; i < num_sb; i++) {
+        const uint32_t ft = cdf[3];
+        const int sc = 15 - RangeEnc::ilog(ft - 1);
+        rc.encode(0, cdf[0] << sc, ft << sc);
+        if (cdf[3] + 128 > 32767)
+            for (int k = 0; k < 4; k++) cdf[k] = (cdf[k] >> 1) + k + 1;
+        for (int k = 0; k < 4; k++) cdf[k] += 128;
+    }
+    *slack = rc.finish(bytes);
+    return 0;
+}
+
+int pixfmt_info(int pix_fmt, int *planes, int *depth)
+{
+    switch (pix_fmt) {                    // allowed_pix_fmts, ffv2enc.c:596-601
+    case FFV2AMD_PIX_GRAY8:       *planes = 1; *depth = 8;  return 0;
+    case FFV2AMD_PIX_YUV444P:
+    case FFV2AMD_PIX_GBRP:        *planes = 3; *depth = 8;  return 0;
+    case FFV2AMD_PIX_YUV444P10LE:
+    case FFV2AMD_PIX_GBRP10LE:    *planes = 3; *depth = 10; return 0;
+    case FFV2AMD_PIX_YUV444P12LE:
+    case FFV2AMD_PIX_GBRP12LE:    *planes = 3; *depth = 12; return 0;
+    }
+    return FFV2AMD_ERR_INVAL;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct ffv2amd_encoder {
+    ffv2amd_info info{};
+    FFV2Geom geom{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // shared tables
+    int64_t  *d_thr = nullptr;
+    uint16_t *d_lds_scan = nullptr;
+    uint8_t  *d_prefix = nullptr;
+    int prefix_len = 0, slack = 0;
+    // per-batch workspace
+    uint32_t *d_codes = nullptr, *d_bitoff = nullptr;
+    int32_t  *d_status = nullptr;
+    // single-frame host path
+    uint8_t  *d_frame = nullptr, *d_pkt = nullptr;
+    uint32_t *d_meta = nullptr;          // [0] size, [1] status
+    int32_t  *d_w1 = nullptr;
+    uint8_t  *h_frame = nullptr, *h_pkt = nullptr;
+    uint32_t *h_meta = nullptr;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return FFV2AMD_ERR_DEVICE; } } while (0)
+
+extern "C" {
+
+const char *ffv2amd_version(void) { return FFV2AMD_VERSION; }
+
+uint32_t ffv2amd_coded_gain(int64_t energy) { return coded_gain_host(energy); }
+
+int ffv2amd_range_prefix(int pix_fmt, int num_sb, uint8_t *out, size_t cap, int *slack_bits)
+{
+    std::vector<uint8_t> b;
+    int sl = 0;
+    int r = range_prefix(pix_fmt, num_sb, b, &sl);
+    if (r < 0) return r;
+    if (b.size() > cap) return FFV2AMD_ERR_NOSPACE;
+    if (out) memcpy(out, b.data(), b.size());
+    if (slack_bits) *slack_bits = sl;
+    return (int)b.size();
+}
+
+void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
+    (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
+    (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
+    if (e->h_frame) (void)hipHostFree(e->h_frame);
+    if (e->h_pkt) (void)hipHostFree(e->h_pkt);
+    if (e->h_meta) (void)hipHostFree(e->h_meta);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix_fmt,
+                           int device, int max_batch)
+{
+    if (!out) return FFV2AMD_ERR_INVAL;
+    *out = nullptr;
+    int planes, depth;
+    if (pixfmt_info(pix_fmt, &planes, &depth) < 0) return FFV2AMD_ERR_INVAL;
+    if (width < 1 || height < 1 || width > 65536 || height > 65536 || max_batch < 1) return FFV2AMD_ERR_INVAL;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        fprintf(stderr, "ffv2amd: no usable HIP device %d (found %d) -- this library has no CPU path\n", device, ndev);
+        return FFV2AMD_ERR_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+
+    ffv2amd_encoder *e = new (std::nothrow) ffv2amd_encoder;
+    if (!e) return FFV2AMD_ERR_NOMEM;
+    e->device = device;
+    ffv2amd_info &in = e->info;
+    in.width = width; in.height = height; in.pix_fmt = pix_fmt;
+    in.planes = planes; in.depth = depth;
+    in.num_sb_x = (width + 63) / 64;                         // ffv2enc.c:503-504
+    in.num_sb_y = (height + 63) / 64;
+    in.block_planes = in.num_sb_x * in.num_sb_y * planes;
+    in.max_batch = max_batch;
+    const int bps = depth > 8 ? 2 : 1;
+    in.row_pitch = align_up((size_t)width * bps, 128);
+    in.plane_stride = align_up(in.row_pitch * height, 256);
+    in.frame_stride = in.plane_stride * planes;
+    in.tstage_bytes_per_frame = (size_t)planes * width * height * bps +
+                                (size_t)planes * (64 * in.num_sb_x) * (64 * in.num_sb_y) * 4;
+
+    std::vector<uint8_t> prefix;
+    int r = range_prefix(pix_fmt, in.num_sb_x * in.num_sb_y, prefix, &e->slack);
+    if (r < 0) { delete e; return r; }
+    e->prefix_len = (int)prefix.size();
+    // worst case raw bits per block-plane: c0 (|c0| < 2^22: 43+1 bits) + 13 gains
+    // (<= 2^15: 31 bits each) + 4 tx bits per superblock  -> < 58 bytes
+    in.packet_cap = align_up((size_t)e->prefix_len + 16 + (size_t)in.block_planes * 58 + 64, 256);
+
+    FFV2Geom &g = e->geom;
+    g.width = width; g.height = height; g.depth = depth; g.planes = planes; g.bytes_per_sample = bps;
+    g.nsx = in.num_sb_x; g.nsy = in.num_sb_y; g.nblk = in.block_planes;
+    g.row_pitch = in.row_pitch; g.plane_stride = in.plane_stride; g.frame_stride = in.frame_stride;
+
+    std::call_once(g_thr_once, build_gain_table);
+    uint16_t lds_scan[4096];
+    for (int q = 0; q < 4096; q++)
+        lds_scan[q] = (uint16_t)((FFV2_SCAN_LUT[q] >> 6) * 65 + (FFV2_SCAN_LUT[q] & 63));
+
+#define CK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(hipGetLastError())); \
+    ffv2amd_encoder_destroy(e); return FFV2AMD_ERR_DEVICE; } } while (0)
+    CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CK(hipMalloc(&e->d_thr, sizeof(int64_t) * GAIN_TABLE_N));
+    CK(hipMemcpy(e->d_thr, g_thr.data(), sizeof(int64_t) * GAIN_TABLE_N, hipMemcpyHostToDevice));
+    CK(hipMalloc(&e->d_lds_scan, sizeof(lds_scan)));
+    CK(hipMemcpy(e->d_lds_scan, lds_scan, sizeof(lds_scan), hipMemcpyHostToDevice));
+    CK(hipMalloc(&e->d_prefix, align_up(prefix.size(), 16)));
+    CK(hipMemcpy(e->d_prefix, prefix.data(), prefix.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&e->d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * g.nblk * (size_t)max_batch));
+    CK(hipMalloc(&e->d_bitoff, sizeof(uint32_t) * g.nblk * (size_t)max_batch));
+    CK(hipMalloc(&e->d_status, sizeof(int32_t) * (size_t)max_batch));
+    CK(hipMalloc(&e->d_frame, in.frame_stride));
+    CK(hipMalloc(&e->d_pkt, in.packet_cap));
+    CK(hipMalloc(&e->d_meta, 16));
+    CK(hipMalloc(&e->d_w1, sizeof(int32_t) * g.nblk));
+    CK(hipHostMalloc(&e->h_frame, in.frame_stride, hipHostMallocDefault));
+    CK(hipHostMalloc(&e->h_pkt, in.packet_cap, hipHostMallocDefault));
+    CK(hipHostMalloc(&e->h_meta, 16, hipHostMallocDefault));
+#undef CK
+    memset(e->h_frame, 0, in.frame_stride);
+    *out = e;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encoder_info(const ffv2amd_encoder *e, ffv2amd_info *info)
+{
+    if (!e || !info) return FFV2AMD_ERR_INVAL;
+    *info = e->info;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_tstage_device(ffv2amd_encoder *e, int nframes, const void *d_frames,
+                          int32_t *d_coef, int64_t *d_energy, void *stream)
+{
+    if (!e || !d_frames || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int32_t) * nframes, s));
+    FFV2TStageArgs a{};
+    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
+    a.coef = d_coef; a.energy = d_energy; a.codes = nullptr; a.W = nullptr;
+    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
+    a.status = e->d_status;
+    HIPCHK(ffv2_launch_tstage(a, s));
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_frames,
+                                int qp, const int32_t *d_W,
+                                void *d_packets, size_t packet_stride,
+                                uint32_t *d_sizes, int32_t *d_status, void *stream)
+{
+    if (!e || !d_frames || !d_packets || !d_sizes || nframes < 1 || nframes > e->info.max_batch)
+        return FFV2AMD_ERR_INVAL;
+    if (packet_stride & 3) return FFV2AMD_ERR_INVAL;
+    if (qp < 0) return FFV2AMD_ERR_INVAL;
+    if (qp != 0) return FFV2AMD_ERR_UNSUPPORTED;              // PVQ path: SURVEY.md 8(f) rank 1
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    int32_t *status = d_status ? d_status : e->d_status;
+    HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, s));
+
+    FFV2TStageArgs a{};
+    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
+    a.coef = nullptr; a.energy = nullptr; a.codes = e->d_codes; a.W = d_W;
+    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
+    a.status = status;
+    HIPCHK(ffv2_launch_tstage(a, s));
+
+    FFV2EStageArgs b{};
+    b.g = e->geom; b.nframes = nframes; b.codes = e->d_codes; b.bitoff = e->d_bitoff;
+    b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
+    b.sizes = d_sizes; b.status = status;
+    b.prefix = e->d_prefix; b.prefix_len = e->prefix_len; b.slack_bits = e->slack;
+    // raw header: pix_fmt & 15 (daala_entropy.c:406), then Exp-Golomb(qp = 0) = "1"
+    b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
+    b.header_nbits = 5;
+    HIPCHK(ffv2_launch_estage_qp0(b, s));
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encode_frame(ffv2amd_encoder *e,
+                         const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                         int qp, const int32_t *W,
+                         uint8_t *out, size_t out_cap, size_t *out_size)
+{
+    if (!e || !data || !linesize || !out || !out_size) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    const size_t row_bytes = (size_t)in.width * (in.depth > 8 ? 2 : 1);
+    for (int p = 0; p < in.planes; p++) {
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+        for (int y = 0; y < in.height; y++)
+            memcpy(e->h_frame + (size_t)p * in.plane_stride + (size_t)y * in.row_pitch,
+                   data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
+    }
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->d_frame, e->h_frame, in.frame_stride, hipMemcpyHostToDevice, s));
+    const int32_t *dW = nullptr;
+    if (W) {
+        HIPCHK(hipMemcpyAsync(e->d_w1, W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, s));
+        dW = e->d_w1;
+    }
+    int r = ffv2amd_encode_batch_device(e, 1, e->d_frame, qp, dW, e->d_pkt, in.packet_cap,
+                                        e->d_meta, (int32_t *)(e->d_meta + 1), s);
+    if (r < 0) return r;
+    HIPCHK(hipMemcpyAsync(e->h_meta, e->d_meta, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_pkt, e->d_pkt, in.packet_cap, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int32_t st = (int32_t)e->h_meta[1];
+    if (st < 0) return st;
+    const size_t n = e->h_meta[0];
+    if (n == 0) return FFV2AMD_ERR_DEVICE;
+    if (n > out_cap) return FFV2AMD_ERR_NOSPACE;
+    memcpy(out, e->h_pkt, n);
+    *out_size = n;
+    return FFV2AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Internal launcher interface between the C-ABI (ffv2_capi.cpp) and the gfx950
+// kernels (ffv2_kernels.hip).  Not installed; the public surface is include/ffv2_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FFV2_NUM_BANDS     13
+#define FFV2_CODES_PER_BP  16   // uint32 slots per block-plane record (see below)
+
+// Per-block-plane record written by the T-stage for the E-stage:
+//   [0]      c0 as int32 (coding index 0 = coefficient (x=0,y=1))
+//   [1..13]  coded band gains (ffv2enc.c:174)
+//   [14]     raw bits this block-plane emits (its 14 Exp-Golomb codes + sign)
+//   [15]     0
+struct FFV2Geom {
+    int width, height, depth, planes, bytes_per_sample;
+    int nsx, nsy, nblk;               // nblk = nsx*nsy*planes
+    size_t row_pitch, plane_stride, frame_stride;
+};
+
+struct FFV2TStageArgs {
+    FFV2Geom g;
+    int nframes;
+    const uint8_t *frames;
+    int32_t  *coef;                   // optional [nframes][nblk][4096]
+    int64_t  *energy;                 // optional [nframes][nblk][13]
+    uint32_t *codes;                  // optional [nframes][nblk][16]
+    const int32_t *W;                 // optional [nframes][nblk]
+    const int64_t *gain_thr;          // gain_thr[n] = least energy whose coded gain is >= n+1
+    int gain_n;                       // entries in gain_thr
+    const uint16_t *lds_scan;         // q -> dword offset (y*65+x) in the LDS raster
+    int32_t *status;                  // [nframes] sticky per-frame error
+};
+
+struct FFV2EStageArgs {
+    FFV2Geom g;
+    int nframes;
+    const uint32_t *codes;            // [nframes][nblk][16]
+    uint32_t *bitoff;                 // [nframes][nblk] scratch: raw-bit offset of each block-plane
+    uint8_t  *packets;                // [nframes][packet_stride], zeroed by the caller
+    size_t    packet_stride;
+    uint32_t *sizes;                  // [nframes]
+    int32_t  *status;                 // [nframes]
+    const uint8_t *prefix;            // range-coded prefix bytes (data independent at qp 0)
+    int prefix_len, slack_bits;
+    uint32_t header_bits, header_nbits; // raw bits in front of the first superblock
+};
+
+hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s);
+hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s);

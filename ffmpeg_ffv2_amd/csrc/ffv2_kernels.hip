@@ -1,0 +1,529 @@
+// ffv2_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the FFV2 encode hot path.
+//
+// T-stage (one launch per batch of frames), fused per 64x64 superblock-plane:
+//   level shift        reference libavcodec/ffv2.c:26-38   (ref_2_coeffs_*)
+//   lapping pre-filter ffv2.c:183-214,285-304 driven by ffv2enc.c:345-366
+//   2-D lifting DCT    ffv2.c:4950-4960 over od_bin_fdct64 ffv2.c:4678-4812
+//   scan               ffv2.c:62-79 (raster_to_coding) + zigzags.h
+//   band energies/gain ffv2enc.c:163-166,174
+// E-stage at qp == 0 (ffv2enc.c:105-123,148-150,174,197 + daala_entropy.c:227-270,
+// 698-721): every data-dependent symbol is a raw bit, so the packet tail is an
+// exclusive prefix sum over code lengths followed by a scatter of the codes.
+//
+// Work decomposition: ONE wavefront (64 lanes) owns one 64x64 block-plane.  It
+// stages the 96x96 halo tile (16 samples each side, what the two lapping passes
+// reach) once, as int16, in 19.5 KB of LDS; the same LDS is then re-used as the
+// int32 transposition buffer between the column and row DCT passes and as the
+// raster buffer for the scan-order gather.  Eight such workgroups fit a CU
+// (2 waves per SIMD).  HBM sees each source sample ~once (halo re-reads hit L2:
+// block ids are dealt so that an XCD owns a contiguous run of superblocks) and
+// each coefficient exactly once, written in coding order, 256 B per wave store.
+// Integer lifting only; no MFMA.
+//
+// Exactness notes:
+//  * int16 staging is lossless: |sample| <= 2048 after the level shift, the
+//    lapping filter's largest output L1 gain is 3.353, so |H| <= 6.9e3 and
+//    |H then V| <= 2.31e4 < 32767 (tools/derive_lifting_ir.py analysis).
+//  * v_mul_i32_i24 gives the same low 32 bits as the reference's wrapping int32
+//    multiply whenever |operand| < 2^23; with the bound above the largest operand
+//    of any multiply in either DCT pass is < 2.1e6.
+#include "ffv2_kernels.h"
+
+#include "gen/fdct64_net.h"
+
+#define FFV2_RSH1(a)            (((a) + (int)((unsigned)(a) >> 31)) >> 1)
+#define FFV2_MULRS(a, K, R, S)  ((__mul24((a), (K)) + (R)) >> (S))
+
+namespace {
+
+constexpr int TILE      = 96;          // 64 + 2*16 halo
+constexpr int TPITCH    = 104;         // int16 per tile row: 208 B = 13 x 16 B (odd multiple -> b128 conflict free)
+constexpr int XPITCH    = 65;          // dwords per row of the int32 transposition / raster buffers
+constexpr int LDS_BYTES = TILE * TPITCH * 2;   // 19968 >= 64*65*4 = 16640
+static_assert(64 * XPITCH * 4 <= LDS_BYTES, "transposition buffer must fit in the tile");
+
+__device__ constexpr int OUTR[64] = { FDCT64_OUT_REG_LIST };
+
+// reference libavcodec/ffv2.c:168-172 (lap_filt_params_32): 16 scales, 15+15 lifting taps
+__device__ constexpr int LAPP[46] = {
+    91, 70, 68, 67, 67, 67, 67, 66, 66, 67, 67, 66, 67, 67, 67, 70,
+    -32, -41, -42, -41, -40, -38, -36, -34, -32, -29, -24, -19, -14, -9, -5,
+    58, 52, 50, 48, 45, 43, 40, 38, 35, 32, 29, 24, 18, 13, 8,
+};
+
+// 32-tap lapping pre-filter, in place (ffv2.c:183-214)
+__device__ __forceinline__ void lap32(int (&x)[32])
+{
+    int t[32];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[31 - i] = x[i] - x[31 - i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[15 - i] = x[15 - i] - (t[16 + i] >> 1);
+#pragma unroll
+    for (int i = 16; i < 32; i++) {
+        int v = __mul24(t[i], LAPP[i - 16]) >> 6;
+        t[i] = v + (v > 0);
+    }
+#pragma unroll
+    for (int i = 31; i > 16; i--) {
+        t[i]     += (__mul24(t[i - 1], LAPP[i - 1]) + 32) >> 6;
+        t[i - 1] += (__mul24(t[i], LAPP[i + 14]) + 32) >> 6;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] += t[31 - i] >> 1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        x[i]      = t[i];
+        x[16 + i] = t[15 - i] - t[16 + i];
+    }
+}
+
+__device__ __forceinline__ int lo16(uint32_t w) { return (int)(w << 16) >> 16; }
+__device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Coded band gain, bit-identical to the host's
+//   (uint32)(float)pow((double)(sqrtf((float)e) + FLT_EPSILON), (double)(1.0f/1.5f))
+// (ffv2enc.c:131-138,166,174) without evaluating pow on the device: thr[n] is the
+// least energy whose coded gain is >= n+1, tabulated by the host with its own libm
+// at encoder creation; the float estimate below only seeds the search.
+__device__ __forceinline__ uint32_t coded_gain(long long e, const int64_t *thr, int n, bool &out_of_table)
+{
+    float g = sqrtf((float)e);
+    int v = (int)exp2f(log2f(g + 1e-30f) * 0.6666667f);
+    v = v < 0 ? 0 : (v > n ? n : v);
+    while (v > 0 && thr[v - 1] > e) v--;
+    while (v < n && thr[v] <= e) v++;
+    if (v >= n) out_of_table = true;
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ int golomb_len(uint32_t val)      // ffv2enc.c:105-123
+{
+    return 2 * (31 - __clz(val + 1)) + 1;
+}
+
+// ---------------------------------------------------------------------------
+// T-stage
+// ---------------------------------------------------------------------------
+template <int BPS, bool WRITE_COEF>
+__global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs a)
+{
+    __shared__ int4 lds_raw[LDS_BYTES / 16];
+    int16_t  *tile = reinterpret_cast<int16_t *>(lds_raw);
+    int      *xb   = reinterpret_cast<int *>(lds_raw);
+
+    const FFV2Geom &g = a.g;
+    const int lane = threadIdx.x;
+
+    // XCD-aware block id: ids b and b+8 share an XCD (round-robin dispatch), so
+    // give each XCD one contiguous run of block-planes -> neighbouring tiles,
+    // which share their 32-sample halos, meet in the same L2.
+    const long long total = (long long)a.nframes * g.nblk;
+    const long long chunk = (total + 7) >> 3;
+    const long long id = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= chunk || id >= total) return;
+    const int f   = (int)(id / g.nblk);
+    const int bp  = (int)(id - (long long)f * g.nblk);
+    const int sb  = bp / g.planes;
+    const int p   = bp - sb * g.planes;
+    const int sby = sb / g.nsx;
+    const int sbx = sb - sby * g.nsx;
+
+    const uint8_t *plane = a.frames + (size_t)f * g.frame_stride + (size_t)p * g.plane_stride;
+    const int sh = 12 - g.depth;
+    const int x_org = sbx * 64 - 16, y_org = sby * 64 - 16;
+    const bool seamL = sbx > 0, seamR = sbx + 1 < g.nsx;
+    const bool seamT = sby > 0, seamB = sby + 1 < g.nsy;
+    const int grid_h = g.nsy * 64;
+
+    // ---- phase A: coalesced 16-byte reads of the 96x96 halo tile -> int16 LDS ----
+    {
+        constexpr int EPV = 16 / BPS;            // samples per 16-byte vector
+        constexpr int VPR = TILE / EPV;          // vectors per tile row (6 | 12)
+        constexpr int PER_LANE = TILE * VPR / 64;  // 9 | 18
+        uint4 v[PER_LANE];
+#pragma unroll
+        for (int it = 0; it < PER_LANE; it++) {
+            const int vi = it * 64 + lane;
+            const int r = vi / VPR, cv = vi - r * VPR;
+            const int y = y_org + r, x0 = x_org + cv * EPV;
+            const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
+            v[it] = ok ? *reinterpret_cast<const uint4 *>(plane + (size_t)y * g.row_pitch + (size_t)x0 * BPS)
+                       : make_uint4(0, 0, 0, 0);
+        }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int it = 0; it < PER_LANE; it++) {
+            const int vi = it * 64 + lane;
+            const int r = vi / VPR, cv = vi - r * VPR;
+            const int y = y_org + r, x0 = x_org + cv * EPV;
+            const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
+            int nvalid = ok ? g.width - x0 : 0;      // samples of this vector inside the picture
+            const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
+            int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + cv * EPV);
+            if (BPS == 1) {
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int e0 = 2 * k, e1 = 2 * k + 1;
+                    int s0 = (int)((w[e0 >> 2] >> ((e0 & 3) * 8)) & 0xff);
+                    int s1 = (int)((w[e1 >> 2] >> ((e1 & 3) * 8)) & 0xff);
+                    s0 = e0 < nvalid ? (s0 << sh) - 2048 : 0;
+                    s1 = e1 < nvalid ? (s1 << sh) - 2048 : 0;
+                    o[k] = pack16(s0, s1);
+                }
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+            } else {
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int s0 = (int)(w[k] & 0xffff), s1 = (int)(w[k] >> 16);
+                    if (2 * k < nvalid)     bad |= (uint32_t)s0 >> g.depth;
+                    if (2 * k + 1 < nvalid) bad |= (uint32_t)s1 >> g.depth;
+                    s0 = 2 * k     < nvalid ? (s0 << sh) - 2048 : 0;
+                    s1 = 2 * k + 1 < nvalid ? (s1 << sh) - 2048 : 0;
+                    o[k] = pack16(s0, s1);
+                }
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (__any(bad != 0) && lane == 0)
+            atomicMin(&a.status[f], -34);            // FFV2AMD_ERR_RANGE
+    }
+    __syncthreads();
+
+    // ---- phase B: horizontal lapping on the two vertical seams (rows in parallel) ----
+    // 96 rows x 2 seams = 192 filter instances = 3 rounds of 64 lanes.
+#pragma unroll 1
+    for (int round = 0; round < 3; round++) {
+        const int inst = round * 64 + lane;
+        const bool right = inst >= TILE;
+        const int r = right ? inst - TILE : inst;
+        const int y = y_org + r;
+        const bool act = (right ? seamR : seamL) & (y >= 0) & (y < grid_h);
+        if (__any(act)) {
+            int x[32];
+            const int4 *src = reinterpret_cast<const int4 *>(tile + r * TPITCH + (right ? 64 : 0));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int4 w = src[q];
+                x[8 * q + 0] = lo16(w.x); x[8 * q + 1] = hi16(w.x);
+                x[8 * q + 2] = lo16(w.y); x[8 * q + 3] = hi16(w.y);
+                x[8 * q + 4] = lo16(w.z); x[8 * q + 5] = hi16(w.z);
+                x[8 * q + 6] = lo16(w.w); x[8 * q + 7] = hi16(w.w);
+            }
+            lap32(x);
+            if (act) {
+                // keep the half that lies inside this block: left seam -> taps 16..31
+                // (tile cols 16..31), right seam -> taps 0..15 (tile cols 64..79)
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    o[k] = right ? pack16(x[2 * k], x[2 * k + 1]) : pack16(x[16 + 2 * k], x[17 + 2 * k]);
+                int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + (right ? 64 : 16));
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: vertical lapping on the two horizontal seams (columns in parallel) ----
+#pragma unroll 1
+    for (int seam = 0; seam < 2; seam++) {
+        if (seam == 0 ? !seamT : !seamB) continue;           // wave-uniform
+        const int rb = seam == 0 ? 0 : 64;
+        int x[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) x[k] = tile[(rb + k) * TPITCH + 16 + lane];
+        lap32(x);
+        if (seam == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) tile[(16 + k) * TPITCH + 16 + lane] = (int16_t)x[16 + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) tile[(64 + k) * TPITCH + 16 + lane] = (int16_t)x[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: column transforms (lane = column), then transpose through LDS ----
+    int x[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+        x[k] = tile[(16 + k) * TPITCH + 16 + lane];
+        // keep the 16-bit provenance from the optimiser: with known-bits it rewrites
+        // __mul24 into a plain 32-bit multiply and then selects the slow v_mul_lo_u32
+        asm("" : "+v"(x[k]));
+    }
+    __syncthreads();                                         // tile is dead: LDS becomes int32 [64][65]
+    FDCT64_NET(x);
+#pragma unroll
+    for (int v = 0; v < 64; v++) xb[lane * XPITCH + v] = x[OUTR[v]];      // tmp[64*col + v], ffv2.c:4957
+    __syncthreads();
+
+    // ---- phase E: row transforms (lane = vertical frequency v) ----
+#pragma unroll
+    for (int k = 0; k < 64; k++) x[k] = xb[k * XPITCH + lane];            // tmp + v, stride 64, ffv2.c:4959
+    __syncthreads();
+    FDCT64_NET(x);
+#pragma unroll
+    for (int u = 0; u < 64; u++) xb[lane * XPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
+    __syncthreads();
+
+    // ---- phase F: scan-order gather, coalesced store, band energies ----
+    // coding index q = 64*j + lane.  Bands (ffv2.c:100-120): q=0 "DC" slot, then
+    // [1,16) [16,24) [24,32) [32,64) | [64,96) [96,128) | [128,256) [256,384) [384,512)
+    // [512,1024) [1024,1536) [1536,2048) [2048,4096].
+    int32_t *coef = WRITE_COEF ? a.coef + ((size_t)f * g.nblk + bp) * 4096 : nullptr;
+    auto fetch = [&](int j) -> int {
+        const int q = j * 64 + lane;
+        const int c = xb[a.lds_scan[q]];
+        if (WRITE_COEF) coef[q] = c;
+        return c;
+    };
+    long long acc[9];          // j=0 row, j=1 row, then bands 6..12
+    const int c_first = fetch(0);
+    acc[0] = (long long)c_first * c_first;
+    {
+        const int c = fetch(1);
+        acc[1] = (long long)c * c;
+    }
+    {
+        // band b (6..12) covers rows j in [JB[b-6], JB[b-5])
+        constexpr int JB[8] = { 2, 4, 6, 8, 16, 24, 32, 64 };
+#pragma unroll
+        for (int b = 0; b < 7; b++) {
+            long long s = 0;
+#pragma unroll 4
+            for (int j = JB[b]; j < JB[b + 1]; j++) {
+                const int c = fetch(j);
+                s += (long long)c * c;
+            }
+            acc[2 + b] = s;
+        }
+    }
+    long long en[FFV2_NUM_BANDS];
+    en[0]  = wave_sum((lane >= 1  && lane < 16) ? acc[0] : 0);
+    en[1]  = wave_sum((lane >= 16 && lane < 24) ? acc[0] : 0);
+    en[2]  = wave_sum((lane >= 24 && lane < 32) ? acc[0] : 0);
+    en[3]  = wave_sum(lane >= 32 ? acc[0] : 0);
+    en[4]  = wave_sum(lane < 32 ? acc[1] : 0);
+    en[5]  = wave_sum(lane >= 32 ? acc[1] : 0);
+#pragma unroll
+    for (int b = 6; b < 13; b++) en[b] = wave_sum(acc[b - 4]);
+    const int c0 = __shfl(c_first, 0, 64);
+
+    long long my = 0;
+#pragma unroll
+    for (int b = 0; b < 13; b++) my = lane == b ? en[b] : my;
+    if (a.energy && lane < 13)
+        a.energy[((size_t)f * g.nblk + bp) * FFV2_NUM_BANDS + lane] = my;
+
+    if (a.codes) {
+        // lanes 0..12: band gains; lane 13: the "DC" slot; the reference's last band
+        // also squares the int32 that follows temp2[] (phantom W)
+        if (lane == 12 && a.W) {
+            const long long w = a.W[(size_t)f * g.nblk + bp];
+            my += w * w;
+        }
+        bool oot = false;
+        uint32_t val = 0;
+        int nb = 0;
+        if (lane < 13) {
+            val = coded_gain(my, a.gain_thr, a.gain_n, oot);
+            nb = golomb_len(val);
+        } else if (lane == 13) {
+            val = (uint32_t)c0;
+            const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
+            nb = golomb_len(mag) + (c0 != 0);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nb += __shfl_xor(nb, m, 64);
+        uint32_t *rec = a.codes + ((size_t)f * g.nblk + bp) * FFV2_CODES_PER_BP;
+        if (lane < 13)       rec[1 + lane] = val;
+        else if (lane == 13) rec[0] = val;
+        else if (lane == 14) rec[14] = (uint32_t)nb;
+        else if (lane == 15) rec[15] = 0;
+        if (__any(oot) && lane == 0)
+            atomicMin(&a.status[f], -34);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// E-stage, qp == 0
+// ---------------------------------------------------------------------------
+// raw bit t of the frame's raw stream lives in packet byte total-1-(t>>3), bit t&7
+// (daala_entropy.c:259,700: bytes are written from the buffer end backwards; the
+// last, partial byte is OR-ed into the final range byte, :719-721).
+__device__ __forceinline__ void or_raw_byte(uint8_t *pkt, uint32_t total, uint32_t raw_byte, uint32_t v)
+{
+    const uint32_t addr = total - 1 - raw_byte;
+    atomicOr(reinterpret_cast<uint32_t *>(pkt + (addr & ~3u)), v << ((addr & 3u) * 8));
+}
+
+struct BitSink {
+    uint8_t *pkt;
+    uint32_t total, byte;
+    unsigned long long win;
+    int nwin;
+    __device__ void init(uint8_t *p, uint32_t tot, uint32_t bitpos)
+    {
+        pkt = p; total = tot; byte = bitpos >> 3; nwin = (int)(bitpos & 7); win = 0;
+    }
+    __device__ void put(unsigned long long v, int n)          // n <= 56
+    {
+        win |= v << nwin;
+        nwin += n;
+        while (nwin >= 8) {
+            or_raw_byte(pkt, total, byte++, (uint32_t)(win & 0xff));
+            win >>= 8;
+            nwin -= 8;
+        }
+    }
+    __device__ void flush()
+    {
+        if (nwin > 0 && win) or_raw_byte(pkt, total, byte, (uint32_t)(win & 0xff));
+    }
+};
+
+__device__ __forceinline__ unsigned long long spread_bits(uint32_t x32)
+{
+    unsigned long long x = x32;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8))  & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4))  & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2))  & 0x3333333333333333ull;
+    x = (x | (x << 1))  & 0x5555555555555555ull;
+    return x;
+}
+
+// Exp-Golomb of ffv2enc.c:105-123 as one LSB-first bit pattern: for every bit of
+// val+1 below its MSB, MSB first, the pair [0, bit]; then a single 1.
+__device__ __forceinline__ void put_golomb(BitSink &s, uint32_t val)
+{
+    const uint32_t v = val + 1;
+    const int nb = 31 - __clz(v);
+    unsigned long long pat = 1ull << (2 * nb);
+    if (nb > 0) {
+        const uint32_t m = v & ((1u << nb) - 1);
+        const uint32_t r = __brev(m) >> (32 - nb);           // first-emitted bit at position 0
+        pat |= spread_bits(r) << 1;
+    }
+    const int len = 2 * nb + 1;
+    if (len > 32) {
+        s.put(pat & 0xffffffffull, 32);
+        s.put(pat >> 32, len - 32);
+    } else {
+        s.put(pat, len);
+    }
+}
+
+// One workgroup per frame: exclusive scan of the per-block-plane bit counts
+// (each superblock is preceded by its 4 transform-type bits, ffv2enc.c:197), packet
+// size, range-coded prefix, header bits.
+__global__ __launch_bounds__(1024) void ffv2_escan_kernel(const FFV2EStageArgs a)
+{
+    __shared__ uint32_t part[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = a.g.nblk, P = a.g.planes;
+    const uint32_t *codes = a.codes + (size_t)f * n * FFV2_CODES_PER_BP;
+    uint32_t *bitoff = a.bitoff + (size_t)f * n;
+    const int ipt = (n + 1023) / 1024;
+    const int i0 = tid * ipt, i1 = min(n, i0 + ipt);
+
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; i++)
+        sum += codes[(size_t)i * FFV2_CODES_PER_BP + 14] + ((i % P) == 0 ? 4u : 0u);
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                      // Hillis-Steele inclusive scan
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t total_bits = a.header_nbits + part[1023];
+    uint32_t run = a.header_nbits + part[tid] - sum;          // exclusive
+    for (int i = i0; i < i1; i++) {
+        const uint32_t tx = (i % P) == 0 ? 4u : 0u;
+        bitoff[i] = run + tx;
+        run += codes[(size_t)i * FFV2_CODES_PER_BP + 14] + tx;
+    }
+
+    const uint32_t slack = (uint32_t)a.slack_bits;
+    const uint32_t nraw = total_bits > slack ? (total_bits - slack + 7) >> 3 : 0;
+    const uint32_t total = (uint32_t)a.prefix_len + nraw;
+    uint8_t *pkt = a.packets + (size_t)f * a.packet_stride;
+    const bool fits = (size_t)total + 4 <= a.packet_stride;
+    if (tid == 0) {
+        a.sizes[f] = fits ? total : 0;
+        if (!fits) atomicMin(&a.status[f], -28);              // FFV2AMD_ERR_NOSPACE
+    }
+    if (!fits) return;
+    for (int i = tid; i < a.prefix_len; i += 1024)            // OR: the last byte is shared with raw bits
+        atomicOr(reinterpret_cast<uint32_t *>(pkt + (i & ~3)), (uint32_t)a.prefix[i] << ((i & 3) * 8));
+    if (tid == 0) {
+        BitSink s;
+        s.init(pkt, total, 0);
+        s.put(a.header_bits, (int)a.header_nbits);
+        s.flush();
+    }
+}
+
+// One thread per block-plane: its 14 codes (+ sign) at its bit offset.
+__global__ __launch_bounds__(256) void ffv2_epack_kernel(const FFV2EStageArgs a)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.g.nblk) return;
+    const uint32_t total = a.sizes[f];
+    if (total == 0) return;
+    const uint32_t *rec = a.codes + ((size_t)f * a.g.nblk + i) * FFV2_CODES_PER_BP;
+    BitSink s;
+    s.init(a.packets + (size_t)f * a.packet_stride, total, a.bitoff[(size_t)f * a.g.nblk + i]);
+    const int c0 = (int)rec[0];
+    const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
+    put_golomb(s, mag);                                       // ffv2enc.c:148-150
+    if (c0) s.put(c0 < 0 ? 1u : 0u, 1);
+#pragma unroll 1
+    for (int b = 0; b < FFV2_NUM_BANDS; b++)
+        put_golomb(s, rec[1 + b]);                            // ffv2enc.c:174
+    s.flush();
+}
+
+}  // namespace
+
+hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
+{
+    const long long total = (long long)a.nframes * a.g.nblk;
+    const long long chunk = (total + 7) / 8;
+    const dim3 grid((unsigned)(chunk * 8)), block(64);
+    const bool wc = a.coef != nullptr;
+    if (a.g.bytes_per_sample == 1) {
+        if (wc) hipLaunchKernelGGL((ffv2_tstage_kernel<1, true>),  grid, block, 0, s, a);
+        else    hipLaunchKernelGGL((ffv2_tstage_kernel<1, false>), grid, block, 0, s, a);
+    } else {
+        if (wc) hipLaunchKernelGGL((ffv2_tstage_kernel<2, true>),  grid, block, 0, s, a);
+        else    hipLaunchKernelGGL((ffv2_tstage_kernel<2, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(ffv2_escan_kernel, dim3(a.nframes), dim3(1024), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ffv2_epack_kernel, dim3((a.g.nblk + 255) / 256, a.nframes), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

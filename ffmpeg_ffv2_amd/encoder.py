@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference encoder's interface for the FFV2 hot path.
+
+Names follow reference libavcodec/ffv2enc.c: `FFV2Encoder(...)` is `ffv2enc_init`
+(:495), `encode2()` is `ffv2_encode_frame` (:453), `close()` is `ffv2enc_close`
+(:515).  Everything goes through the C-ABI in include/ffv2_amd.h; torch is used
+only to own device memory and streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PIX_FMTS = {  # allowed_pix_fmts, ffv2enc.c:596-601 (AVPixelFormat values of the reference tree)
+    "gray": 8, "yuv444p": 5, "yuv444p10le": 70, "yuv444p12le": 133,
+    "gbrp": 73, "gbrp10le": 77, "gbrp12le": 137,
+}
+
+
+class FFV2Encoder:
+    def __init__(self, width, height, pix_fmt="yuv444p", device=0, max_batch=1):
+        self._lib = _lib.load()
+        if isinstance(pix_fmt, str):
+            if pix_fmt not in PIX_FMTS:
+                # avcodec_open2 refuses pix_fmts outside the whitelist (utils.c:814-822)
+                raise _lib.FFV2Error(-22, "pix_fmt %s" % pix_fmt)
+            pix_fmt = PIX_FMTS[pix_fmt]
+        h = C.c_void_p()
+        _lib.check(self._lib.ffv2amd_encoder_create(C.byref(h), width, height, pix_fmt, device, max_batch),
+                   "ffv2amd_encoder_create")
+        self._h = h
+        self.info = _lib.Info()
+        _lib.check(self._lib.ffv2amd_encoder_info(self._h, C.byref(self.info)), "ffv2amd_encoder_info")
+        self.device = device
+        self.dtype = np.uint8 if self.info.depth == 8 else np.dtype("<u2")
+
+    # -- AVCodec.close --
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ffv2amd_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- AVCodec.encode2: host frame (P,H,W) -> packet bytes --
+    def encode2(self, frame, qp=0, W=None):
+        i = self.info
+        frame = np.ascontiguousarray(frame, self.dtype)
+        assert frame.shape == (i.planes, i.height, i.width), frame.shape
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(i.planes):
+            data[p] = frame[p].ctypes.data
+            ls[p] = frame[p].strides[0]
+        out = np.empty(i.packet_cap, np.uint8)
+        n = C.c_size_t(0)
+        wp = None
+        if W is not None:
+            W = np.ascontiguousarray(W, np.int32)
+            assert W.size == i.block_planes
+            wp = W.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.ffv2amd_encode_frame(self._h, data, ls, qp, wp,
+                                                  out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)),
+                   "ffv2amd_encode_frame")
+        return out[:n.value].tobytes()
+
+    # -- device-resident helpers --
+    def pack_frames(self, frames):
+        """(F,P,H,W) host array -> (F, frame_stride) uint8 host array in the device layout."""
+        i = self.info
+        frames = np.ascontiguousarray(frames, self.dtype)
+        F = frames.shape[0]
+        assert frames.shape[1:] == (i.planes, i.height, i.width)
+        buf = np.zeros((F, i.frame_stride), np.uint8)
+        bps = self.dtype.itemsize if hasattr(self.dtype, "itemsize") else 1
+        raw = frames.view(np.uint8).reshape(F, i.planes, i.height, i.width * bps)
+        for p in range(i.planes):
+            v = buf[:, p * i.plane_stride: p * i.plane_stride + i.row_pitch * i.height]
+            v = v.reshape(F, i.height, i.row_pitch)
+            v[:, :, : i.width * bps] = raw[:, p]
+        return buf
+
+    def upload(self, frames):
+        import torch
+        return torch.from_numpy(self.pack_frames(frames)).to("cuda:%d" % self.device)
+
+    def tstage(self, d_frames, want_coef=True, want_energy=True):
+        """d_frames: torch uint8 (F, frame_stride) on this device -> (coef, energy) torch tensors."""
+        import torch
+        F = d_frames.shape[0]
+        dev = d_frames.device
+        coef = torch.empty((F, self.info.block_planes, 4096), dtype=torch.int32, device=dev) if want_coef else None
+        en = torch.empty((F, self.info.block_planes, 13), dtype=torch.int64, device=dev) if want_energy else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._lib.ffv2amd_tstage_device(self._h, F, d_frames.data_ptr(),
+                                                   coef.data_ptr() if want_coef else None,
+                                                   en.data_ptr() if want_energy else None,
+                                                   C.c_void_p(stream)), "ffv2amd_tstage_device")
+        return coef, en
+
+    def alloc_packets(self, nframes):
+        import torch
+        dev = "cuda:%d" % self.device
+        return (torch.empty((nframes, self.info.packet_cap), dtype=torch.uint8, device=dev),
+                torch.empty((nframes,), dtype=torch.int32, device=dev),
+                torch.empty((nframes,), dtype=torch.int32, device=dev))
+
+    def encode_batch_device(self, d_frames, qp=0, d_W=None, out=None, stream=None):
+        """Asynchronous: frames resident in HBM -> packets resident in HBM.
+        Returns (packets (F,cap) uint8, sizes (F,) int32, status (F,) int32)."""
+        import torch
+        F = d_frames.shape[0]
+        if out is None:
+            out = self.alloc_packets(F)
+        pk, sizes, status = out
+        if stream is None:
+            stream = torch.cuda.current_stream(d_frames.device).cuda_stream
+        _lib.check(self._lib.ffv2amd_encode_batch_device(
+            self._h, F, d_frames.data_ptr(), qp, d_W.data_ptr() if d_W is not None else None,
+            pk.data_ptr(), pk.stride(0), sizes.data_ptr(), status.data_ptr(), C.c_void_p(stream)),
+            "ffv2amd_encode_batch_device")
+        return pk, sizes, status
+
+    @staticmethod
+    def collect(pk, sizes, status):
+        """Synchronise and bring packets to the host as a list of bytes."""
+        sizes = sizes.cpu().numpy()
+        status = status.cpu().numpy()
+        for f, st in enumerate(status):
+            if st < 0:
+                raise _lib.FFV2Error(int(st), "frame %d" % f)
+        hp = pk.cpu().numpy()
+        return [hp[f, : sizes[f]].tobytes() for f in range(hp.shape[0])]

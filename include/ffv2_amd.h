@@ -1,0 +1,118 @@
+/*
+ * ffv2_amd.h -- C-ABI of the MI355X-native FFV2 encode hot path.
+ *
+ * This is the drop-in boundary for the path SURVEY.md section 8 scopes: what
+ * libavcodec/ffv2enc.c does between AVCodec.init / .encode2 / .close
+ * (reference libavcodec/ffv2enc.c:495-513, :453-493, :515-580; the AVCodec
+ * contract itself is libavcodec/avcodec.h:3546-3693, caller encode.c:264-346).
+ * Plain pointers and sizes only: no torch, no C++ types.  INTEGRATION.md shows
+ * the ~40-line AVCodec glue a maintainer adds on the FFmpeg side.
+ *
+ * All entry points return 0 on success or a negative FFV2AMD_ERR_* code; the
+ * values follow AVERROR(errno) so they can be returned from encode2() as is.
+ * There is no CPU fallback: without a usable HIP device every call that needs
+ * the GPU fails with FFV2AMD_ERR_DEVICE.
+ */
+#ifndef FFV2_AMD_H
+#define FFV2_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFV2AMD_OK               0
+#define FFV2AMD_ERR_INVAL      (-22)  /* AVERROR(EINVAL): bad geometry / pix_fmt / argument     */
+#define FFV2AMD_ERR_NOMEM      (-12)  /* AVERROR(ENOMEM)                                        */
+#define FFV2AMD_ERR_DEVICE     (-5)   /* AVERROR(EIO): HIP runtime / device failure             */
+#define FFV2AMD_ERR_NOSPACE    (-28)  /* AVERROR(ENOSPC): caller's packet buffer too small      */
+#define FFV2AMD_ERR_RANGE      (-34)  /* AVERROR(ERANGE): a sample exceeds the declared depth,
+                                          or a band gain left the quantiser table                */
+#define FFV2AMD_ERR_ABORT      (-1)   /* AVERROR(EPERM): the reference would av_assert0 -> abort
+                                          (daala_entropy.c:336; qp > 0 only)                     */
+#define FFV2AMD_ERR_UNSUPPORTED (-38) /* AVERROR(ENOSYS)                                        */
+
+/* AVPixelFormat values the reference encoder accepts (ffv2enc.c:596-601; numeric
+ * values of libavutil/pixfmt.h in the reference tree, little-endian host). */
+#define FFV2AMD_PIX_YUV444P      5
+#define FFV2AMD_PIX_GRAY8        8
+#define FFV2AMD_PIX_YUV444P10LE 70
+#define FFV2AMD_PIX_GBRP        73
+#define FFV2AMD_PIX_GBRP10LE    77
+#define FFV2AMD_PIX_YUV444P12LE 133
+#define FFV2AMD_PIX_GBRP12LE    137
+
+typedef struct ffv2amd_encoder ffv2amd_encoder;
+
+/* Geometry derived at init (ffv2enc.c:500-504). */
+typedef struct ffv2amd_info {
+    int width, height, pix_fmt;
+    int planes, depth;
+    int num_sb_x, num_sb_y;        /* ceil(w/64), ceil(h/64)                              */
+    int block_planes;              /* num_sb_x*num_sb_y*planes: 64x64 blocks per frame     */
+    int max_batch;                 /* frames one *_device call may carry                   */
+    size_t packet_cap;             /* upper bound of one packet in bytes (qp == 0)         */
+    size_t tstage_bytes_per_frame; /* algorithmic HBM bytes of the T-stage, SURVEY.md 8(d):
+                                      P*W*H*bytes_in + P*(64nsx)*(64nsy)*4                 */
+    /* layout the *_device entry points expect for frames resident in HBM */
+    size_t row_pitch;              /* bytes, multiple of 16, >= width*bytes_per_sample     */
+    size_t plane_stride;           /* bytes, row_pitch*height rounded up to 256            */
+    size_t frame_stride;           /* bytes, plane_stride*planes                           */
+} ffv2amd_info;
+
+/* == AVCodec.init (ffv2enc.c:495).  device = HIP ordinal.  max_batch >= 1 sizes the
+ * device workspace (frames in flight per call; BASELINE.json's "slices" in SURVEY's
+ * reading). */
+int  ffv2amd_encoder_create(ffv2amd_encoder **enc, int width, int height, int pix_fmt,
+                            int device, int max_batch);
+/* == AVCodec.close (ffv2enc.c:515). NULL is accepted. */
+void ffv2amd_encoder_destroy(ffv2amd_encoder *enc);
+int  ffv2amd_encoder_info(const ffv2amd_encoder *enc, ffv2amd_info *info);
+
+/* == AVCodec.encode2 (ffv2enc.c:453): one frame in host memory -> one packet in host
+ * memory.  Reads data[p]/linesize[p] for p < planes exactly as ref2coeff does
+ * (ffv2enc.c:471-474), qp = avctx->global_quality (ffv2enc.c:460).
+ * W: optional phantom coefficient per block-plane, index (sby*nsx+sbx)*planes+p
+ * (the reference reads temp2[4096]); NULL means 0 = clang-built
+ * reference. */
+int  ffv2amd_encode_frame(ffv2amd_encoder *enc,
+                          const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                          int qp, const int32_t *W,
+                          uint8_t *out, size_t out_cap, size_t *out_size);
+
+/* Same step for `nframes` (<= max_batch) frames already resident in HBM in the
+ * layout ffv2amd_info describes; packets stay in HBM:
+ *   d_packets[f*packet_stride ...], d_sizes[f] (uint32 bytes).
+ * d_W: device int32[nframes][block_planes] or NULL.  stream: hipStream_t or NULL.
+ * Asynchronous with respect to the host; per-frame status lands in d_status[f]
+ * (0 or a negative FFV2AMD_ERR_*), if d_status != NULL. */
+int  ffv2amd_encode_batch_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,
+                                 int qp, const int32_t *d_W,
+                                 void *d_packets, size_t packet_stride,
+                                 uint32_t *d_sizes, int32_t *d_status, void *stream);
+
+/* T-stage alone (level shift, lapping, 2-D lifting DCT, scan, band energies):
+ *   d_coef   int32[nframes][block_planes][4096] coding order      (may be NULL)
+ *   d_energy int64[nframes][block_planes][13]   phantom W excluded (may be NULL)
+ * Used by the parity tests and the roofline measurement. */
+int  ffv2amd_tstage_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,
+                           int32_t *d_coef, int64_t *d_energy, void *stream);
+
+/* Host helpers with no GPU work (unit-tested on CPU):
+ * coded band gain for an integer band energy, bit-identical to
+ * (uint32)(float)pow(sqrtf(e)+FLT_EPSILON, 1/1.5f) (ffv2enc.c:166,174) ... */
+uint32_t ffv2amd_coded_gain(int64_t energy);
+/* ... and the data-independent range-coded prefix of a qp==0 packet
+ * (ffv2enc.c:449, :222 through daala_entropy.c:328-379,428-440,624-674):
+ * writes the bytes, returns their count (<0 on error), *slack_bits = free low
+ * bits of the last byte that raw bits are OR-ed into (daala_entropy.c:719-721). */
+int  ffv2amd_range_prefix(int pix_fmt, int num_sb, uint8_t *out, size_t cap, int *slack_bits);
+
+const char *ffv2amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

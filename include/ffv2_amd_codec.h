@@ -1,0 +1,66 @@
+/*
+ * ffv2_amd_codec.h -- AVCodec-shaped host surface of the MI355X FFV2 encoder.
+ *
+ * On a machine with the FFmpeg tree, libavcodec/ffv2enc_amd.c
+ * fills a real `AVCodec` with these three functions.  The GPU box has no FFmpeg,
+ * so this header mirrors only the fields the reference encoder touches
+ * (SURVEY.md section 8(b) "Inputs read" / "Ownership"):
+ *   AVCodecContext: width, height, pix_fmt, global_quality, priv_data
+ *                   (libavcodec/avcodec.h; read at ffv2enc.c:460,474,500-504)
+ *   AVFrame       : data[], linesize[]                       (ffv2enc.c:471-474)
+ *   AVPacket      : data, size + an owner handle in place of AVBufferRef
+ *                   (daala_entropy.c:727-732)
+ * Same names, argument meaning and error behaviour as AVCodec.init / encode2 /
+ * close (avcodec.h:3546-3693): 0 on success, negative AVERROR otherwise,
+ * *got_packet_ptr = 1 with exactly one packet per frame, no delay.
+ */
+#ifndef FFV2_AMD_CODEC_H
+#define FFV2_AMD_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct FFV2AMDCodecContext {
+    int width, height;
+    int pix_fmt;            /* enum AVPixelFormat value                       */
+    int global_quality;     /* qp (ffv2enc.c:460); default 0                  */
+    int hip_device;         /* extension: HIP ordinal, default 0              */
+    void *priv_data;        /* owned by init/close                            */
+} FFV2AMDCodecContext;
+
+typedef struct FFV2AMDFrame {
+    const uint8_t *data[4];
+    ptrdiff_t linesize[4];
+    int64_t pts;
+} FFV2AMDFrame;
+
+typedef struct FFV2AMDPacket {
+    uint8_t *data;          /* malloc'ed by encode2, freed by ffv2amd_packet_unref */
+    int size;
+    int64_t pts, dts;       /* stamped from the frame, as encode.c:329-330 does */
+} FFV2AMDPacket;
+
+typedef struct FFV2AMDCodecDescriptor {
+    const char *name;           /* "ffv2"                                      */
+    const char *long_name;
+    const int *pix_fmts;        /* terminated by -1 (AV_PIX_FMT_NONE)          */
+    int capabilities;           /* AV_CODEC_CAP_DR1 | AV_CODEC_CAP_EXPERIMENTAL */
+    int caps_internal;          /* INIT_THREADSAFE | INIT_CLEANUP              */
+    int priv_data_size;
+} FFV2AMDCodecDescriptor;
+
+const FFV2AMDCodecDescriptor *ffv2amd_codec_descriptor(void);   /* ffv2enc.c:603-617 */
+int  ffv2amd_codec_init(FFV2AMDCodecContext *avctx);             /* ffv2enc.c:495     */
+int  ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
+                           const FFV2AMDFrame *frame, int *got_packet_ptr);  /* :453 */
+int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:515     */
+void ffv2amd_packet_unref(FFV2AMDPacket *pkt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

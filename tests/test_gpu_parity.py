@@ -1,0 +1,199 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C-ABI, against the CPU oracle on the same seeded inputs -- bit exact."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from ffmpeg_ffv2_amd import frames as synth  # noqa: E402
+
+
+def _enc(w, h, fmt, max_batch=1):
+    from ffmpeg_ffv2_amd import FFV2Encoder, build
+    build.build()
+    return FFV2Encoder(w, h, fmt, device=0, max_batch=max_batch)
+
+
+def _first_diff(a, b):
+    idx = np.argwhere(a != b)
+    return idx[0] if len(idx) else None
+
+
+CASES = [
+    ("gray", 1, 64, 64, 8), ("gray", 1, 100, 150, 8), ("yuv444p", 3, 240, 320, 8),
+    ("yuv444p10le", 3, 128, 192, 10), ("yuv444p12le", 3, 130, 200, 12), ("gbrp", 3, 64, 200, 8),
+    ("gbrp10le", 3, 300, 70, 10), ("gray", 1, 17, 9, 8), ("yuv444p", 3, 65, 129, 8),
+]
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", CASES)
+@pytest.mark.parametrize("kind", ["S1", "S2"])
+def test_tstage_coefficients_and_energies(oracle, fmt, P, H, W, depth, kind):
+    enc = _enc(W, H, fmt)
+    fr = synth.make(kind, 3, P, H, W, depth)
+    coef_o, en_o = oracle.tstage(fr, fmt)
+    coef, en = enc.tstage(enc.upload(fr[None]))
+    coef = coef.cpu().numpy()[0]
+    en = en.cpu().numpy()[0]
+    d = _first_diff(coef, coef_o)
+    assert d is None, "first coefficient mismatch at block-plane %d, coding index %d: %d vs %d" % (
+        d[0], d[1], coef[tuple(d)], coef_o[tuple(d)])
+    assert np.array_equal(en, en_o)
+    enc.close()
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", CASES)
+def test_packets_host_boundary(oracle, fmt, P, H, W, depth):
+    enc = _enc(W, H, fmt)
+    for n, kind in enumerate(["S1", "S2", "S2"]):
+        fr = synth.make(kind, n, P, H, W, depth)
+        assert enc.encode2(fr) == oracle.encode(fr, fmt)
+    # extremes: flat black / white / mid
+    for v in (0, (1 << depth) - 1, 1 << (depth - 1)):
+        fr = np.full((P, H, W), v, synth.dtype_for(depth))
+        assert enc.encode2(fr) == oracle.encode(fr, fmt)
+    enc.close()
+
+
+def test_survey_known_answers():
+    """SURVEY.md section 8 KATs straight through the HIP path (no oracle involved)."""
+    enc = _enc(64, 64, "gray")
+    assert enc.encode2(np.full((1, 64, 64), 128, np.uint8)).hex() == "007ffe18"
+    assert enc.encode2(np.full((1, 64, 64), 255, np.uint8)).hex() == "001fffa8002218"
+    assert enc.encode2(np.full((1, 64, 64), 128, np.uint8), W=[9]).hex() == "00063ffe18"
+    enc.close()
+    enc = _enc(320, 240, "yuv444p")
+    fr = np.random.default_rng(1234).integers(0, 256, (5, 3, 240, 320), dtype=np.uint8)
+    pk = b"".join(enc.encode2(fr[i]) for i in range(5))
+    assert (len(pk), hashlib.md5(pk).hexdigest()) == (9565, "08700eaee86fe100fef32f338264c357")
+    enc.close()
+    enc = _enc(192, 128, "yuv444p10le")
+    fr = np.random.default_rng(99).integers(0, 1024, (2, 3, 128, 192), dtype=np.uint16)
+    pk = b"".join(enc.encode2(fr[i]) for i in range(2))
+    assert (len(pk), hashlib.md5(pk).hexdigest()) == (1145, "fb85644e9fc183e66a576ce8bd11bd6e")
+    enc.close()
+    enc = _enc(150, 100, "gray")
+    y, x = np.mgrid[0:100, 0:150]
+    pk = enc.encode2(((3 * x + 5 * y) % 256).astype(np.uint8)[None])
+    assert (len(pk), hashlib.md5(pk).hexdigest()) == (192, "d3154b32ce9f33ccc860bd195259f3d8")
+    enc.close()
+    enc = _enc(320, 256, "yuv444p")
+    assert len(enc.encode2(np.full((3, 256, 320), 128, np.uint8))) == 117
+    assert len(enc.encode2(np.full((3, 256, 320), 255, np.uint8))) == 282
+    w = np.repeat(np.arange(4), 15).astype(np.int32)
+    assert len(enc.encode2(np.full((3, 256, 320), 128, np.uint8), W=w)) == 128
+    enc.close()
+
+
+def test_batch_device_api_with_phantom_w(oracle):
+    import torch
+    W, H, fmt, P, depth, F = 320, 240, "yuv444p", 3, 8, 6
+    enc = _enc(W, H, fmt, max_batch=F)
+    fr = np.stack([synth.make("S2" if n % 2 else "S1", n, P, H, W, depth) for n in range(F)])
+    rng = np.random.default_rng(3)
+    Wv = rng.integers(-3000, 3000, (F, enc.info.block_planes)).astype(np.int32)
+    out = enc.encode_batch_device(enc.upload(fr), d_W=torch.from_numpy(Wv).cuda())
+    pk = enc.collect(*out)
+    for n in range(F):
+        assert pk[n] == oracle.encode(fr[n], fmt, W=Wv[n]), "frame %d" % n
+    # smaller batch through the same encoder, no W
+    pk = enc.collect(*enc.encode_batch_device(enc.upload(fr[:2])))
+    for n in range(2):
+        assert pk[n] == oracle.encode(fr[n], fmt)
+    enc.close()
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth,kind", [
+    ("yuv444p", 3, 1080, 1920, 8, "S2"),          # BASELINE config 2 (restated 4:4:4)
+    ("yuv444p10le", 3, 2160, 3840, 10, "S1"),     # BASELINE config 3, headline
+])
+def test_full_size_frame_bit_exact(oracle, fmt, P, H, W, depth, kind):
+    enc = _enc(W, H, fmt)
+    fr = synth.make(kind, 0, P, H, W, depth)
+    assert enc.encode2(fr) == oracle.encode(fr, fmt)
+    enc.close()
+
+
+def test_full_size_properties_8k12():
+    """BASELINE config 5 size: properties that need no oracle run.
+    * determinism, * frame independence inside a batch (ffv2enc.c:461-469: no
+    inter-frame state), * a frame whose picture is confined to one superblock only
+    changes that superblock's neighbourhood: the 4 SBs sharing lapped seams."""
+    W, H, fmt, P, depth = 7680, 4320, "yuv444p12le", 3, 12
+    enc = _enc(W, H, fmt, max_batch=2)
+    a = synth.structured(0, P, H, W, depth)
+    b = a.copy()
+    b[:, 640:704, 1280:1344] ^= 0x155                     # SB (x=20, y=10) only
+    d = enc.upload(np.stack([a, b]))
+    coef, en = enc.tstage(d, want_coef=False)
+    en = en.cpu().numpy().reshape(2, enc.info.num_sb_y, enc.info.num_sb_x, P, 13)
+    changed = np.argwhere((en[0] != en[1]).any(axis=(2, 3)))
+    assert len(changed) > 0
+    assert all(abs(y - 10) <= 1 and abs(x - 20) <= 1 for y, x in changed)
+    p1 = enc.collect(*enc.encode_batch_device(d))
+    p2 = enc.collect(*enc.encode_batch_device(torch_flip(d)))
+    assert p1[0] == p2[1] and p1[1] == p2[0]
+    enc.close()
+
+
+def torch_flip(d):
+    import torch
+    return torch.flip(d, dims=[0]).contiguous()
+
+
+def test_sample_out_of_range_is_an_error():
+    from ffmpeg_ffv2_amd import FFV2Error
+    enc = _enc(192, 128, "yuv444p10le")
+    fr = np.full((3, 128, 192), 512, np.uint16)
+    fr[1, 77, 100] = 1024                                  # needs 11 bits
+    with pytest.raises(FFV2Error) as e:
+        enc.encode2(fr)
+    assert e.value.code == -34
+    enc.close()
+
+
+def test_qp_nonzero_is_refused_not_approximated():
+    from ffmpeg_ffv2_amd import FFV2Error
+    enc = _enc(64, 64, "gray")
+    with pytest.raises(FFV2Error) as e:
+        enc.encode2(np.zeros((1, 64, 64), np.uint8), qp=16)
+    assert e.value.code == -38
+    enc.close()
+
+
+def test_avcodec_shaped_shim(oracle):
+    """init / encode2 / close of ffv2enc_amd.c (the AVCodec surface)."""
+    from ffmpeg_ffv2_amd import _lib
+
+    class Ctx(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("pix_fmt", C.c_int),
+                    ("global_quality", C.c_int), ("hip_device", C.c_int), ("priv_data", C.c_void_p)]
+
+    class Frame(C.Structure):
+        _fields_ = [("data", C.c_void_p * 4), ("linesize", C.c_ssize_t * 4), ("pts", C.c_int64)]
+
+    class Packet(C.Structure):
+        _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_int), ("pts", C.c_int64), ("dts", C.c_int64)]
+
+    lib = _lib.load()
+    ctx = Ctx(320, 240, 5, 0, 0, None)
+    assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
+    for n in range(3):
+        fr = synth.noise(n, 3, 240, 320, 8)
+        f = Frame()
+        for p in range(3):
+            f.data[p] = fr[p].ctypes.data
+            f.linesize[p] = fr[p].strides[0]
+        f.pts = 40 + n
+        pkt = Packet()
+        got = C.c_int(0)
+        assert lib.ffv2amd_codec_encode2(C.byref(ctx), C.byref(pkt), C.byref(f), C.byref(got)) == 0
+        assert got.value == 1 and pkt.pts == 40 + n and pkt.dts == 40 + n
+        assert bytes(pkt.data[: pkt.size]) == oracle.encode(fr, "yuv444p")
+        lib.ffv2amd_packet_unref(C.byref(pkt))
+    assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0 and not ctx.priv_data
+    bad = Ctx(320, 240, 0, 0, 0, None)                     # yuv420p is not accepted (ffv2enc.c:596-601)
+    assert lib.ffv2amd_codec_init(C.byref(bad)) == -22

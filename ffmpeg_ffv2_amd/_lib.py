@@ -44,6 +44,14 @@ def load():
     if not os.path.exists(SO):
         raise RuntimeError("%s is missing: build it with `python -m ffmpeg_ffv2_amd.build` "
                            "(hipcc, gfx950). There is no CPU fallback." % SO)
+    # torch wheels bundle their own libamdhip64.so (same SONAME, libamdhip64.so.7, as
+    # /opt/rocm's).  Whichever HIP runtime is mapped first serves every later NEEDED
+    # entry with that SONAME; if ours came first torch would map a second runtime and
+    # one of the two would see no GPU.  So: torch (when present) goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO)
     lib.ffv2amd_version.restype = C.c_char_p
     lib.ffv2amd_encoder_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -308,7 +308,7 @@ int ffv2amd_tstage_device(ffv2amd_encoder *e, int nframes, const void *d_frames,
 {
     if (!e || !d_frames || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
     HIPCHK(hipSetDevice(e->device));
-    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
     HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int32_t) * nframes, s));
     FFV2TStageArgs a{};
     a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
@@ -330,7 +330,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (qp < 0) return FFV2AMD_ERR_INVAL;
     if (qp != 0) return FFV2AMD_ERR_UNSUPPORTED;              // PVQ path: SURVEY.md 8(f) rank 1
     HIPCHK(hipSetDevice(e->device));
-    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
     int32_t *status = d_status ? d_status : e->d_status;
     HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, s));
     HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, s));

@@ -32,7 +32,7 @@ class FFV2Encoder:
         self.info = _lib.Info()
         _lib.check(self._lib.ffv2amd_encoder_info(self._h, C.byref(self.info)), "ffv2amd_encoder_info")
         self.device = device
-        self.dtype = np.uint8 if self.info.depth == 8 else np.dtype("<u2")
+        self.dtype = np.dtype(np.uint8) if self.info.depth == 8 else np.dtype("<u2")
 
     # -- AVCodec.close --
     def close(self):
@@ -76,7 +76,7 @@ class FFV2Encoder:
         F = frames.shape[0]
         assert frames.shape[1:] == (i.planes, i.height, i.width)
         buf = np.zeros((F, i.frame_stride), np.uint8)
-        bps = self.dtype.itemsize if hasattr(self.dtype, "itemsize") else 1
+        bps = self.dtype.itemsize
         raw = frames.view(np.uint8).reshape(F, i.planes, i.height, i.width * bps)
         for p in range(i.planes):
             v = buf[:, p * i.plane_stride: p * i.plane_stride + i.row_pitch * i.height]

@@ -85,7 +85,7 @@ int  ffv2amd_encode_frame(ffv2amd_encoder *enc,
 /* Same step for `nframes` (<= max_batch) frames already resident in HBM in the
  * layout ffv2amd_info describes; packets stay in HBM:
  *   d_packets[f*packet_stride ...], d_sizes[f] (uint32 bytes).
- * d_W: device int32[nframes][block_planes] or NULL.  stream: hipStream_t or NULL.
+ * d_W: device int32[nframes][block_planes] or NULL.  stream: hipStream_t (NULL = the default stream).
  * Asynchronous with respect to the host; per-frame status lands in d_status[f]
  * (0 or a negative FFV2AMD_ERR_*), if d_status != NULL. */
 int  ffv2amd_encode_batch_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,

@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- FFV2 encode throughput on MI355X (one process per GPU).
+
+metric  : Mpix/s encode (BASELINE.json), luma pixels W*H per second, whole job.
+workload: BASELINE config 3 as it reaches encode2():
+          3840x2160 planar 4:4:4 10-bit (yuv444p10le), qp = global_quality = 0,
+          "slices=8" read as 8 frames in flight per step.  Frames are synthetic
+          (S1 structured / S2 uniform noise, seeded), resident in HBM before the
+          timed region; packets land in HBM.
+step    : one ffv2amd_encode_batch_device call = T-stage kernel + E-stage kernels
+          over the 8 frames, coefficients materialised in HBM (the reference's
+          temp2[]; --no-coef measures the fully fused qp=0 variant instead).
+N > 1   : frames are independent (no inter-frame state, ffv2enc.c:461-469), so
+          each rank encodes its own frames: weak scaling, no data-path collective;
+          RCCL is used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (width, height, pix_fmt, depth)
+    "C2": (1920, 1080, "yuv444p", 8),
+    "C3": (3840, 2160, "yuv444p10le", 10),
+    "C4": (3840, 2160, "yuv444p", 8),
+    "C5": (7680, 4320, "yuv444p12le", 12),
+}
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--no-coef", action="store_true", help="do not materialise coefficients (fused qp=0 path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth
+    W, H, fmt, depth = CONFIGS[args.config]
+    F = args.frames_per_step
+    enc = FFV2Encoder(W, H, fmt, device=local, max_batch=F)
+    P = enc.info.planes
+
+    # synthetic frames: even index structured, odd index noise; rank-dependent seeds
+    host_frames = np.stack([synth.make("S1" if n % 2 == 0 else "S2", rank * F + n, P, H, W, depth)
+                            for n in range(F)])
+    d_frames = enc.upload(host_frames)
+    out = enc.alloc_packets(F)
+    if not args.no_coef:
+        coef = torch.empty((F, enc.info.block_planes, 4096), dtype=torch.int32, device=dev)
+        enc.set_coef_sink(coef)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc.encode_batch_device(d_frames, out=out, stream=stream)
+    barrier()
+    enc.profile(True)
+    enc.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode_batch_device(d_frames, out=out, stream=stream)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    t_ms, e_ms, launches = enc.profile_read()
+    enc.profile(False)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    packets = enc.collect(*out)            # also raises on any per-frame error status
+
+    result = None
+    if rank == 0:
+        frames_total = world * F * args.steps
+        mpix = frames_total * W * H / elapsed / 1e6
+        t_kernel_ms = t_ms / max(launches, 1)
+        alg_bytes = enc.info.tstage_bytes_per_frame * F
+        achieved = alg_bytes / (t_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("frames_per_launch") == F and bool(tj.get("coef_writeback")) == (not args.no_coef):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpix/s encode (4K yuv420p10, slices=8) at 1/2/4/8 GPUs; bit-exact vs CPU",
+            "value": round(mpix, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d %s (4:4:4 restatement of BASELINE config %s), qp=0, "
+                                   "%d frames in flight per step per GPU, frames resident in HBM"
+                                   % (W, H, fmt, args.config[1], F),
+                       "frames_per_step_per_gpu": F,
+                       "coef_writeback": not args.no_coef,
+                       "parallelism": "frame-parallel x%d, no data-path collective" % world,
+                       "packet_bytes_frame0": len(packets[0])},
+            "roofline": {"bound": "hbm", "kernel": "ffv2_tstage_kernel",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_avg": round(t_kernel_ms, 4),
+                         "estage_ms_avg": round(e_ms / max(launches, 1), 4),
+                         "launches_timed": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # CPU baseline: the oracle (C restatement, byte-identical to the reference on
+            # its known answers) on a bounded sample of the SAME frames, one host core.
+            from tests import oracle_lib
+            oracle = oracle_lib.load()
+            n_done, tcpu, ok = 0, 0.0, True
+            while n_done < F and tcpu < args.cpu_seconds:
+                c0 = time.perf_counter()
+                ref = oracle.encode(host_frames[n_done], fmt)
+                tcpu += time.perf_counter() - c0
+                ok = ok and (ref == packets[n_done])
+                n_done += 1
+            result["cpu_baseline"] = {
+                "value": round(n_done * W * H / tcpu / 1e6, 2), "unit": "Mpix/s", "cores": 1, "kind": "port",
+                "sample": "%d of the %d benchmark frames (%dx%d %s), oracle/libffv2_oracle.so, gcc -O2, 1 thread"
+                          % (n_done, F, W, H, fmt),
+                "host_cores_available": os.cpu_count(),
+                "gpu_packets_match_cpu": bool(ok)}
+            if not ok:
+                result["error"] = "GPU packets differ from the CPU oracle"
+        print(json.dumps(result))
+    enc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None and result.get("error"):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -182,6 +182,14 @@ struct ffv2amd_encoder {
     int32_t  *d_w1 = nullptr;
     uint8_t  *h_frame = nullptr, *h_pkt = nullptr;
     uint32_t *h_meta = nullptr;
+    // options
+    int32_t *coef_sink = nullptr;
+    bool profiling = false;
+    struct EvTriple { hipEvent_t a, b, c; };
+    std::vector<EvTriple> ev_pool;       // reused
+    size_t ev_used = 0;
+    double prof_t = 0, prof_e = 0;
+    int prof_n = 0;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -216,6 +224,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     if (e->h_frame) (void)hipHostFree(e->h_frame);
     if (e->h_pkt) (void)hipHostFree(e->h_pkt);
     if (e->h_meta) (void)hipHostFree(e->h_meta);
+    for (auto &t : e->ev_pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -267,9 +276,16 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     g.row_pitch = in.row_pitch; g.plane_stride = in.plane_stride; g.frame_stride = in.frame_stride;
 
     std::call_once(g_thr_once, build_gain_table);
-    uint16_t lds_scan[4096];
-    for (int q = 0; q < 4096; q++)
-        lds_scan[q] = (uint16_t)((FFV2_SCAN_LUT[q] >> 6) * 65 + (FFV2_SCAN_LUT[q] & 63));
+    // phase-F scan table: [i][lane][e] -> byte offset of coding index
+    // q = 256*(2i + e/4) + 4*lane + e%4 in the raster buffer (row pitch 69 dwords)
+    static uint16_t lds_scan[4096];
+    for (int i = 0; i < 8; i++)
+        for (int l = 0; l < 64; l++)
+            for (int e = 0; e < 8; e++) {
+                const int q = 256 * (2 * i + e / 4) + 4 * l + (e & 3);
+                lds_scan[(i * 64 + l) * 8 + e] =
+                    (uint16_t)(((FFV2_SCAN_LUT[q] >> 6) * 69 + (FFV2_SCAN_LUT[q] & 63)) * 4);
+            }
 
 #define CK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(hipGetLastError())); \
     ffv2amd_encoder_destroy(e); return FFV2AMD_ERR_DEVICE; } } while (0)
@@ -340,7 +356,25 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     a.coef = nullptr; a.energy = nullptr; a.codes = e->d_codes; a.W = d_W;
     a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
     a.status = status;
+    a.coef = e->coef_sink;
+    ffv2amd_encoder::EvTriple *ev = nullptr;
+    if (e->profiling) {
+        if (e->ev_used == e->ev_pool.size()) {
+            if (e->ev_pool.size() >= 8192) {                 // drain before growing without bound
+                double t, x; int n;
+                ffv2amd_profile_read(e, &t, &x, &n);
+                e->prof_t += t; e->prof_e += x; e->prof_n += n;
+            } else {
+                ffv2amd_encoder::EvTriple t{};
+                HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.c));
+                e->ev_pool.push_back(t);
+            }
+        }
+        ev = &e->ev_pool[e->ev_used++];
+        HIPCHK(hipEventRecord(ev->a, s));
+    }
     HIPCHK(ffv2_launch_tstage(a, s));
+    if (ev) HIPCHK(hipEventRecord(ev->b, s));
 
     FFV2EStageArgs b{};
     b.g = e->geom; b.nframes = nframes; b.codes = e->d_codes; b.bitoff = e->d_bitoff;
@@ -351,6 +385,41 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
     b.header_nbits = 5;
     HIPCHK(ffv2_launch_estage_qp0(b, s));
+    if (ev) HIPCHK(hipEventRecord(ev->c, s));
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *e, int32_t *d_coef)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    e->coef_sink = d_coef;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_profile_enable(ffv2amd_encoder *e, int on)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    e->profiling = on != 0;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_profile_read(ffv2amd_encoder *e, double *tstage_ms, double *estage_ms, int *launches)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    double t = e->prof_t, x = e->prof_e;
+    int n = e->prof_n;
+    for (size_t i = 0; i < e->ev_used; i++) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(e->ev_pool[i].c));
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b)); t += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].b, e->ev_pool[i].c)); x += ms;
+        n++;
+    }
+    e->ev_used = 0;
+    e->prof_t = e->prof_e = 0; e->prof_n = 0;
+    if (tstage_ms) *tstage_ms = t;
+    if (estage_ms) *estage_ms = x;
+    if (launches) *launches = n;
     return FFV2AMD_OK;
 }
 

@@ -28,7 +28,7 @@ struct FFV2TStageArgs {
     const int32_t *W;                 // optional [nframes][nblk]
     const int64_t *gain_thr;          // gain_thr[n] = least energy whose coded gain is >= n+1
     int gain_n;                       // entries in gain_thr
-    const uint16_t *lds_scan;         // q -> dword offset (y*65+x) in the LDS raster
+    const uint16_t *lds_scan;         // [8][64][8] byte offsets into the LDS raster, see ffv2_capi.cpp
     int32_t *status;                  // [nframes] sticky per-frame error
 };
 

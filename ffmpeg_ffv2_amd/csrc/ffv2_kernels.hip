@@ -82,13 +82,6 @@ __device__ __forceinline__ int lo16(uint32_t w) { return (int)(w << 16) >> 16; }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
 
-__device__ __forceinline__ long long wave_sum(long long v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
 // Coded band gain, bit-identical to the host's
 //   (uint32)(float)pow((double)(sqrtf((float)e) + FLT_EPSILON), (double)(1.0f/1.5f))
 // (ffv2enc.c:131-138,166,174) without evaluating pow on the device: thr[n] is the
@@ -113,6 +106,49 @@ __device__ __forceinline__ int golomb_len(uint32_t val)      // ffv2enc.c:105-12
 // ---------------------------------------------------------------------------
 // T-stage
 // ---------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// two int16 fields of a dword minus 2048 each (v_pk_sub_i16)
+__device__ __forceinline__ uint32_t pk_sub2048(uint32_t w)
+{
+    s16x2 v = __builtin_bit_cast(s16x2, w);
+    v -= (s16x2)(2048);
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// inclusive prefix sum over the 64 lanes, DPP only (no LDS crossbar)
+__device__ __forceinline__ int wave_iscan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// 64-bit per-lane sums are scanned as a 24-bit low part and a high part: both stay
+// below 2^31 over 64 lanes (|coef| < 2^21, at most 32 squares per lane).
+struct Scan64 {
+    int lo, hi;
+    __device__ __forceinline__ void run(unsigned long long a)
+    {
+        lo = wave_iscan((int)(a & 0xffffffull));
+        hi = wave_iscan((int)(a >> 24));
+    }
+    __device__ __forceinline__ long long at(int l) const       // inclusive sum of lanes 0..l, wave-uniform
+    {
+        const unsigned long long h = (unsigned)__builtin_amdgcn_readlane(hi, l);
+        const unsigned long long w = (unsigned)__builtin_amdgcn_readlane(lo, l);
+        return (long long)((h << 24) + w);
+    }
+};
+
+constexpr int RPITCH = 69;   // dwords per row of the raster buffer: the scan-order gather is
+                             // ~2.5x conflict cycles here vs 10.8x at 65 (tools: LDS bank model)
+static_assert(64 * RPITCH * 4 <= LDS_BYTES, "raster buffer must fit in the tile");
+
 template <int BPS, bool WRITE_COEF>
 __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs a)
 {
@@ -144,56 +180,110 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     const bool seamT = sby > 0, seamB = sby + 1 < g.nsy;
     const int grid_h = g.nsy * 64;
 
+    // scan table for phase F, fetched now so that nothing but stores is outstanding
+    // there: [i][lane] 16-byte rows of 8 byte-offsets into the raster buffer, entry e of
+    // row i is coding index q = 256*(2i + e/4) + 4*lane + e%4
+    uint4 lut[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        lut[i] = reinterpret_cast<const uint4 *>(a.lds_scan)[i * 64 + lane];
+
     // ---- phase A: coalesced 16-byte reads of the 96x96 halo tile -> int16 LDS ----
     {
-        constexpr int EPV = 16 / BPS;            // samples per 16-byte vector
-        constexpr int VPR = TILE / EPV;          // vectors per tile row (6 | 12)
+        constexpr int EPV = 16 / BPS;              // samples per 16-byte vector
+        constexpr int VPR = TILE / EPV;            // vectors per tile row (6 | 12)
         constexpr int PER_LANE = TILE * VPR / 64;  // 9 | 18
+        constexpr int RSTEP = 64 / VPR, CSTEP = 64 % VPR;   // vector index += 64  <=>  row += RSTEP, col += CSTEP
+        const bool inside = (x_org >= 0) & (x_org + TILE <= g.width) & (y_org >= 0) & (y_org + TILE <= g.height);
         uint4 v[PER_LANE];
-#pragma unroll
-        for (int it = 0; it < PER_LANE; it++) {
-            const int vi = it * 64 + lane;
-            const int r = vi / VPR, cv = vi - r * VPR;
-            const int y = y_org + r, x0 = x_org + cv * EPV;
-            const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
-            v[it] = ok ? *reinterpret_cast<const uint4 *>(plane + (size_t)y * g.row_pitch + (size_t)x0 * BPS)
-                       : make_uint4(0, 0, 0, 0);
-        }
         uint32_t bad = 0;
+        if (inside) {                              // wave-uniform: no per-sample masking needed
+            int r = lane / VPR, cv = lane - (lane / VPR) * VPR;
+            uint32_t off = (uint32_t)(y_org + r) * (uint32_t)g.row_pitch + (uint32_t)(x_org + cv * EPV) * BPS;
+            const uint32_t step = RSTEP * (uint32_t)g.row_pitch + CSTEP * 16;
+            const uint32_t wrap = (uint32_t)g.row_pitch - VPR * 16;
+            int cvi = cv;
 #pragma unroll
-        for (int it = 0; it < PER_LANE; it++) {
-            const int vi = it * 64 + lane;
-            const int r = vi / VPR, cv = vi - r * VPR;
-            const int y = y_org + r, x0 = x_org + cv * EPV;
-            const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
-            int nvalid = ok ? g.width - x0 : 0;      // samples of this vector inside the picture
-            const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
-            int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + cv * EPV);
-            if (BPS == 1) {
-                uint32_t o[8];
+            for (int it = 0; it < PER_LANE; it++) {
+                v[it] = *reinterpret_cast<const uint4 *>(plane + off);
+                off += step;
+                cvi += CSTEP;
+                if (cvi >= VPR) { cvi -= VPR; off += wrap; }
+            }
+            int doff = r * TPITCH + cv * EPV;      // int16 units
+            cvi = cv;
+            const uint32_t himask = ~(((1u << g.depth) - 1u) * 0x00010001u);
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int e0 = 2 * k, e1 = 2 * k + 1;
-                    int s0 = (int)((w[e0 >> 2] >> ((e0 & 3) * 8)) & 0xff);
-                    int s1 = (int)((w[e1 >> 2] >> ((e1 & 3) * 8)) & 0xff);
-                    s0 = e0 < nvalid ? (s0 << sh) - 2048 : 0;
-                    s1 = e1 < nvalid ? (s1 << sh) - 2048 : 0;
-                    o[k] = pack16(s0, s1);
+            for (int it = 0; it < PER_LANE; it++) {
+                const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
+                int4 *dst = reinterpret_cast<int4 *>(tile + doff);
+                if (BPS == 1) {
+                    uint32_t o[8];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        o[2 * k]     = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u) << sh);
+                        o[2 * k + 1] = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u) << sh);
+                    }
+                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+                } else {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        bad |= w[k] & himask;
+                        o[k] = pk_sub2048(w[k] << sh);
+                    }
+                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                 }
-                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
-            } else {
-                uint32_t o[4];
+                doff += RSTEP * TPITCH + CSTEP * EPV;
+                cvi += CSTEP;
+                if (cvi >= VPR) { cvi -= VPR; doff += TPITCH - VPR * EPV; }
+            }
+        } else {                                   // picture edge: zero outside (ffv2enc.c:69-71), mask per sample
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    int s0 = (int)(w[k] & 0xffff), s1 = (int)(w[k] >> 16);
-                    if (2 * k < nvalid)     bad |= (uint32_t)s0 >> g.depth;
-                    if (2 * k + 1 < nvalid) bad |= (uint32_t)s1 >> g.depth;
-                    s0 = 2 * k     < nvalid ? (s0 << sh) - 2048 : 0;
-                    s1 = 2 * k + 1 < nvalid ? (s1 << sh) - 2048 : 0;
-                    o[k] = pack16(s0, s1);
+            for (int it = 0; it < PER_LANE; it++) {
+                const int vi = it * 64 + lane;
+                const int r = vi / VPR, cv = vi - r * VPR;
+                const int y = y_org + r, x0 = x_org + cv * EPV;
+                const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
+                v[it] = ok ? *reinterpret_cast<const uint4 *>(plane + (size_t)y * g.row_pitch + (size_t)x0 * BPS)
+                           : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int it = 0; it < PER_LANE; it++) {
+                const int vi = it * 64 + lane;
+                const int r = vi / VPR, cv = vi - r * VPR;
+                const int y = y_org + r, x0 = x_org + cv * EPV;
+                const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
+                const int nvalid = ok ? g.width - x0 : 0;    // samples of this vector inside the picture
+                const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
+                int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + cv * EPV);
+                if (BPS == 1) {
+                    uint32_t o[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int e0 = 2 * k, e1 = 2 * k + 1;
+                        int s0 = (int)((w[e0 >> 2] >> ((e0 & 3) * 8)) & 0xff);
+                        int s1 = (int)((w[e1 >> 2] >> ((e1 & 3) * 8)) & 0xff);
+                        s0 = e0 < nvalid ? (s0 << sh) - 2048 : 0;
+                        s1 = e1 < nvalid ? (s1 << sh) - 2048 : 0;
+                        o[k] = pack16(s0, s1);
+                    }
+                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+                } else {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int s0 = (int)(w[k] & 0xffff), s1 = (int)(w[k] >> 16);
+                        if (2 * k < nvalid)     bad |= (uint32_t)s0 >> g.depth;
+                        if (2 * k + 1 < nvalid) bad |= (uint32_t)s1 >> g.depth;
+                        s0 = 2 * k     < nvalid ? (s0 << sh) - 2048 : 0;
+                        s1 = 2 * k + 1 < nvalid ? (s1 << sh) - 2048 : 0;
+                        o[k] = pack16(s0, s1);
+                    }
+                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                 }
-                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
             }
         }
         if (__any(bad != 0) && lane == 0)
@@ -262,7 +352,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     for (int k = 0; k < 64; k++) {
         x[k] = tile[(16 + k) * TPITCH + 16 + lane];
         // keep the 16-bit provenance from the optimiser: with known-bits it rewrites
-        // __mul24 into a plain 32-bit multiply and then selects the slow v_mul_lo_u32
+        // __mul24 into a plain 32-bit multiply and then selects v_mul_lo_u32
         asm("" : "+v"(x[k]));
     }
     __syncthreads();                                         // tile is dead: LDS becomes int32 [64][65]
@@ -277,51 +367,58 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     __syncthreads();
     FDCT64_NET(x);
 #pragma unroll
-    for (int u = 0; u < 64; u++) xb[lane * XPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
+    for (int u = 0; u < 64; u++) xb[lane * RPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
     __syncthreads();
 
-    // ---- phase F: scan-order gather, coalesced store, band energies ----
-    // coding index q = 64*j + lane.  Bands (ffv2.c:100-120): q=0 "DC" slot, then
-    // [1,16) [16,24) [24,32) [32,64) | [64,96) [96,128) | [128,256) [256,384) [384,512)
-    // [512,1024) [1024,1536) [1536,2048) [2048,4096].
-    int32_t *coef = WRITE_COEF ? a.coef + ((size_t)f * g.nblk + bp) * 4096 : nullptr;
-    auto fetch = [&](int j) -> int {
-        const int q = j * 64 + lane;
-        const int c = xb[a.lds_scan[q]];
-        if (WRITE_COEF) coef[q] = c;
-        return c;
-    };
-    long long acc[9];          // j=0 row, j=1 row, then bands 6..12
-    const int c_first = fetch(0);
-    acc[0] = (long long)c_first * c_first;
-    {
-        const int c = fetch(1);
-        acc[1] = (long long)c * c;
-    }
-    {
-        // band b (6..12) covers rows j in [JB[b-6], JB[b-5])
-        constexpr int JB[8] = { 2, 4, 6, 8, 16, 24, 32, 64 };
+    // ---- phase F: scan-order gather, band energies, gains, coalesced 16-byte stores ----
+    // lane owns coding indices q = 256*j + 4*lane + k (j < 16, k < 4) -> x[4j + k].
+    // Bands (ffv2.c:100-120): q=0 "DC" slot, then [1,16) [16,24) [24,32) [32,64) [64,96)
+    // [96,128) [128,256) | [256,384) [384,512) | [512,1024) [1024,1536) [1536,2048) [2048,4096].
 #pragma unroll
-        for (int b = 0; b < 7; b++) {
-            long long s = 0;
-#pragma unroll 4
-            for (int j = JB[b]; j < JB[b + 1]; j++) {
-                const int c = fetch(j);
-                s += (long long)c * c;
-            }
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w[4] = { lut[i].x, lut[i].y, lut[i].z, lut[i].w };
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t off = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
+            x[i * 8 + e] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(xb) + off);
+        }
+    }
+    auto sq = [](int c) { return (unsigned long long)((long long)c * c); };
+    unsigned long long acc[6];
+    acc[0] = sq(x[1]) + sq(x[2]) + sq(x[3]) + (lane == 0 ? 0ull : sq(x[0]));
+    acc[1] = sq(x[4]) + sq(x[5]) + sq(x[6]) + sq(x[7]);
+    {
+        constexpr int XB[5] = { 8, 16, 24, 32, 64 };         // x[] ranges of bands 9..12
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            unsigned long long s = 0;
+#pragma unroll
+            for (int i = XB[b]; i < XB[b + 1]; i++) s += sq(x[i]);
             acc[2 + b] = s;
         }
     }
     long long en[FFV2_NUM_BANDS];
-    en[0]  = wave_sum((lane >= 1  && lane < 16) ? acc[0] : 0);
-    en[1]  = wave_sum((lane >= 16 && lane < 24) ? acc[0] : 0);
-    en[2]  = wave_sum((lane >= 24 && lane < 32) ? acc[0] : 0);
-    en[3]  = wave_sum(lane >= 32 ? acc[0] : 0);
-    en[4]  = wave_sum(lane < 32 ? acc[1] : 0);
-    en[5]  = wave_sum(lane >= 32 ? acc[1] : 0);
+    {
+        Scan64 s;
+        s.run(acc[0]);
+        constexpr int BL[7] = { 3, 5, 7, 15, 23, 31, 63 };   // last lane of bands 0..6 within j = 0
+        long long prev = 0;
 #pragma unroll
-    for (int b = 6; b < 13; b++) en[b] = wave_sum(acc[b - 4]);
-    const int c0 = __shfl(c_first, 0, 64);
+        for (int b = 0; b < 7; b++) {
+            const long long cur = s.at(BL[b]);
+            en[b] = cur - prev;
+            prev = cur;
+        }
+        s.run(acc[1]);
+        en[7] = s.at(31);
+        en[8] = s.at(63) - en[7];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            s.run(acc[2 + b]);
+            en[9 + b] = s.at(63);
+        }
+    }
+    const int c0 = __builtin_amdgcn_readlane(x[0], 0);
 
     long long my = 0;
 #pragma unroll
@@ -347,8 +444,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
             const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
             nb = golomb_len(mag) + (c0 != 0);
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) nb += __shfl_xor(nb, m, 64);
+        nb = __builtin_amdgcn_readlane(wave_iscan(nb), 63);
         uint32_t *rec = a.codes + ((size_t)f * g.nblk + bp) * FFV2_CODES_PER_BP;
         if (lane < 13)       rec[1 + lane] = val;
         else if (lane == 13) rec[0] = val;
@@ -356,6 +452,14 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         else if (lane == 15) rec[15] = 0;
         if (__any(oot) && lane == 0)
             atomicMin(&a.status[f], -34);
+    }
+
+    // coefficients last: 16 stores of 1 KiB per wave, nothing waits on them
+    if (WRITE_COEF) {
+        int4 *cp = reinterpret_cast<int4 *>(a.coef + ((size_t)f * g.nblk + bp) * 4096);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            cp[j * 64 + lane] = make_int4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
     }
 }
 

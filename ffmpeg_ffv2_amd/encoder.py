@@ -125,6 +125,22 @@ class FFV2Encoder:
             "ffv2amd_encode_batch_device")
         return pk, sizes, status
 
+    def set_coef_sink(self, d_coef):
+        """Also keep the coding-order coefficients of every batch encode in HBM
+        (torch int32 (max_batch, block_planes, 4096)) or None to stop."""
+        self._coef_sink = d_coef            # keep it alive
+        _lib.check(self._lib.ffv2amd_encoder_set_coef_sink(
+            self._h, d_coef.data_ptr() if d_coef is not None else None), "set_coef_sink")
+
+    def profile(self, on=True):
+        _lib.check(self._lib.ffv2amd_profile_enable(self._h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self):
+        """-> (tstage_ms_total, estage_ms_total, launches) since the last read."""
+        t, x, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        _lib.check(self._lib.ffv2amd_profile_read(self._h, C.byref(t), C.byref(x), C.byref(n)), "profile_read")
+        return t.value, x.value, n.value
+
     @staticmethod
     def collect(pk, sizes, status):
         """Synchronise and bring packets to the host as a list of bytes."""

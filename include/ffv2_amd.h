@@ -100,6 +100,19 @@ int  ffv2amd_encode_batch_device(ffv2amd_encoder *enc, int nframes, const void *
 int  ffv2amd_tstage_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,
                            int32_t *d_coef, int64_t *d_energy, void *stream);
 
+/* Optional: also materialise the coding-order coefficients of every batch encode
+ * in HBM (what the reference keeps in temp2[], ffv2enc.c:194,201, and what the
+ * qp > 0 quantiser consumes).  d_coef: int32[max_batch][block_planes][4096] or NULL
+ * to turn it off again.  Same kernel launch, no extra pass. */
+int  ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *enc, int32_t *d_coef);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around the
+ * T-stage kernel and around the E-stage kernels of every *_batch_device call.
+ * profile_read waits for the recorded events, returns the summed durations (ms)
+ * and the number of batch launches since the last read, and resets the counters. */
+int  ffv2amd_profile_enable(ffv2amd_encoder *enc, int on);
+int  ffv2amd_profile_read(ffv2amd_encoder *enc, double *tstage_ms, double *estage_ms, int *launches);
+
 /* Host helpers with no GPU work (unit-tested on CPU):
  * coded band gain for an integer band energy, bit-identical to
  * (uint32)(float)pow(sqrtf(e)+FLT_EPSILON, 1/1.5f) (ffv2enc.c:166,174) ... */

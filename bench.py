@@ -53,15 +53,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    # one rank per GPU; FFV2_BENCH_BACKEND=gloo lets several ranks share the single GPU
+    # of a development box to rehearse the N > 1 control path (never used for numbers)
+    backend = os.environ.get("FFV2_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth
     W, H, fmt, depth = CONFIGS[args.config]
@@ -99,7 +104,7 @@ def main():
     enc.profile(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -353,7 +353,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
 
     FFV2TStageArgs a{};
     a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
-    a.coef = nullptr; a.energy = nullptr; a.codes = e->d_codes; a.W = d_W;
+    a.coef = nullptr; a.energy = nullptr; a.codes = e->d_codes; a.bitcnt = e->d_bitoff; a.W = d_W;
     a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
     a.status = status;
     a.coef = e->coef_sink;

@@ -25,6 +25,7 @@ struct FFV2TStageArgs {
     int32_t  *coef;                   // optional [nframes][nblk][4096]
     int64_t  *energy;                 // optional [nframes][nblk][13]
     uint32_t *codes;                  // optional [nframes][nblk][16]
+    uint32_t *bitcnt;                 // with codes: [nframes][nblk] raw bits per block-plane
     const int32_t *W;                 // optional [nframes][nblk]
     const int64_t *gain_thr;          // gain_thr[n] = least energy whose coded gain is >= n+1
     int gain_n;                       // entries in gain_thr
@@ -36,7 +37,7 @@ struct FFV2EStageArgs {
     FFV2Geom g;
     int nframes;
     const uint32_t *codes;            // [nframes][nblk][16]
-    uint32_t *bitoff;                 // [nframes][nblk] scratch: raw-bit offset of each block-plane
+    const uint32_t *bitoff;           // [nframes][nblk] raw bits per block-plane (T-stage bitcnt)
     uint8_t  *packets;                // [nframes][packet_stride], zeroed by the caller
     size_t    packet_stride;
     uint32_t *sizes;                  // [nframes]

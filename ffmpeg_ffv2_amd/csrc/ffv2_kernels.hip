@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         uint32_t *rec = a.codes + ((size_t)f * g.nblk + bp) * FFV2_CODES_PER_BP;
         if (lane < 13)       rec[1 + lane] = val;
         else if (lane == 13) rec[0] = val;
-        else if (lane == 14) rec[14] = (uint32_t)nb;
+        else if (lane == 14) { rec[14] = (uint32_t)nb; a.bitcnt[(size_t)f * g.nblk + bp] = (uint32_t)nb; }
         else if (lane == 15) rec[15] = 0;
         if (__any(oot) && lane == 0)
             atomicMin(&a.status[f], -34);
@@ -469,34 +469,33 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 // raw bit t of the frame's raw stream lives in packet byte total-1-(t>>3), bit t&7
 // (daala_entropy.c:259,700: bytes are written from the buffer end backwards; the
 // last, partial byte is OR-ed into the final range byte, :719-721).
-__device__ __forceinline__ void or_raw_byte(uint8_t *pkt, uint32_t total, uint32_t raw_byte, uint32_t v)
-{
-    const uint32_t addr = total - 1 - raw_byte;
-    atomicOr(reinterpret_cast<uint32_t *>(pkt + (addr & ~3u)), v << ((addr & 3u) * 8));
-}
 
-struct BitSink {
-    uint8_t *pkt;
-    uint32_t total, byte;
+constexpr int EP_THREADS = 256;                  // block-planes per workgroup
+constexpr int EP_WORDS   = 3840;                 // 256 * 58 B worst case, + slack, in 32-bit words
+
+// LSB-first bit writer into a zeroed LDS word buffer (ds_or_b32)
+struct LdsBitSink {
+    uint32_t *buf;
+    uint32_t word;
     unsigned long long win;
     int nwin;
-    __device__ void init(uint8_t *p, uint32_t tot, uint32_t bitpos)
+    __device__ void init(uint32_t *b, uint32_t bitpos)
     {
-        pkt = p; total = tot; byte = bitpos >> 3; nwin = (int)(bitpos & 7); win = 0;
+        buf = b; word = bitpos >> 5; nwin = (int)(bitpos & 31); win = 0;
     }
-    __device__ void put(unsigned long long v, int n)          // n <= 56
+    __device__ void put(unsigned long long v, int n)          // n <= 32
     {
         win |= v << nwin;
         nwin += n;
-        while (nwin >= 8) {
-            or_raw_byte(pkt, total, byte++, (uint32_t)(win & 0xff));
-            win >>= 8;
-            nwin -= 8;
+        if (nwin >= 32) {
+            atomicOr(&buf[word++], (uint32_t)win);
+            win >>= 32;
+            nwin -= 32;
         }
     }
     __device__ void flush()
     {
-        if (nwin > 0 && win) or_raw_byte(pkt, total, byte, (uint32_t)(win & 0xff));
+        if (nwin > 0 && (uint32_t)win) atomicOr(&buf[word], (uint32_t)win);
     }
 };
 
@@ -513,7 +512,7 @@ __device__ __forceinline__ unsigned long long spread_bits(uint32_t x32)
 
 // Exp-Golomb of ffv2enc.c:105-123 as one LSB-first bit pattern: for every bit of
 // val+1 below its MSB, MSB first, the pair [0, bit]; then a single 1.
-__device__ __forceinline__ void put_golomb(BitSink &s, uint32_t val)
+__device__ __forceinline__ void put_golomb(LdsBitSink &s, uint32_t val)
 {
     const uint32_t v = val + 1;
     const int nb = 31 - __clz(v);
@@ -532,77 +531,120 @@ __device__ __forceinline__ void put_golomb(BitSink &s, uint32_t val)
     }
 }
 
-// One workgroup per frame: exclusive scan of the per-block-plane bit counts
-// (each superblock is preceded by its 4 transform-type bits, ffv2enc.c:197), packet
-// size, range-coded prefix, header bits.
-__global__ __launch_bounds__(1024) void ffv2_escan_kernel(const FFV2EStageArgs a)
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *scratch, int tid)
 {
-    __shared__ uint32_t part[1024];
-    const int f = blockIdx.x, tid = threadIdx.x;
-    const int n = a.g.nblk, P = a.g.planes;
-    const uint32_t *codes = a.codes + (size_t)f * n * FFV2_CODES_PER_BP;
-    uint32_t *bitoff = a.bitoff + (size_t)f * n;
-    const int ipt = (n + 1023) / 1024;
-    const int i0 = tid * ipt, i1 = min(n, i0 + ipt);
-
-    uint32_t sum = 0;
-    for (int i = i0; i < i1; i++)
-        sum += codes[(size_t)i * FFV2_CODES_PER_BP + 14] + ((i % P) == 0 ? 4u : 0u);
-    part[tid] = sum;
+    v = (uint32_t)__builtin_amdgcn_readlane(wave_iscan((int)v), 63);
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                      // Hillis-Steele inclusive scan
-        uint32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const uint32_t total_bits = a.header_nbits + part[1023];
-    uint32_t run = a.header_nbits + part[tid] - sum;          // exclusive
-    for (int i = i0; i < i1; i++) {
-        const uint32_t tx = (i % P) == 0 ? 4u : 0u;
-        bitoff[i] = run + tx;
-        run += codes[(size_t)i * FFV2_CODES_PER_BP + 14] + tx;
-    }
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
 
+// E-stage at qp == 0, one launch: workgroup (b, f) owns block-planes [256b, 256b+256)
+// of frame f.  It (1) sums the raw-bit counts of the whole frame (24 KB, L2) to get
+// its own starting bit and the packet size -- the "prefix sum" is recomputed per
+// workgroup instead of being a separate serial kernel --, (2) assembles its codes
+// in LDS with ds_or, (3) streams the finished words to the packet, byte-reversed
+// because raw bytes run backwards from the packet end; only the first/last words,
+// shared with a neighbour workgroup or the range-coded prefix, use global atomics.
+__global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStageArgs a)
+{
+    __shared__ uint32_t bits[EP_WORDS];
+    __shared__ uint32_t scratch[8];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int n = a.g.nblk, P = a.g.planes;
+    const int i0 = blockIdx.x * EP_THREADS;
+    const uint32_t *cnt = a.bitoff + (size_t)f * n;          // raw bits per block-plane (from the T-stage)
+
+    // (1) bits in front of this workgroup, and in the whole frame; every superblock is
+    // preceded by its 4 transform-type bits (ffv2enc.c:197)
+    uint32_t before = 0, all = 0;
+    for (int i = tid; i < n; i += EP_THREADS) {
+        const uint32_t v = cnt[i] + ((i % P) == 0 ? 4u : 0u);
+        all += v;
+        before += i < i0 ? v : 0u;
+    }
+    before = block_sum(before, scratch, tid);
+    all = block_sum(all, scratch + 4, tid);
+
+    const int i = i0 + tid;
+    const bool have = i < n;
+    const uint32_t tx = (have && (i % P) == 0) ? 4u : 0u;
+    const uint32_t mine = have ? cnt[i] + tx : 0u;
+    // exclusive scan of `mine` over the workgroup
+    const uint32_t incl = (uint32_t)wave_iscan((int)mine);
+    __syncthreads();
+    if ((tid & 63) == 63) scratch[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < (tid >> 6); w++) wbase += scratch[w];
+    const uint32_t local_total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+
+    const uint32_t total_bits = a.header_nbits + all;
     const uint32_t slack = (uint32_t)a.slack_bits;
     const uint32_t nraw = total_bits > slack ? (total_bits - slack + 7) >> 3 : 0;
     const uint32_t total = (uint32_t)a.prefix_len + nraw;
     uint8_t *pkt = a.packets + (size_t)f * a.packet_stride;
     const bool fits = (size_t)total + 4 <= a.packet_stride;
-    if (tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         a.sizes[f] = fits ? total : 0;
         if (!fits) atomicMin(&a.status[f], -28);              // FFV2AMD_ERR_NOSPACE
     }
-    if (!fits) return;
-    for (int i = tid; i < a.prefix_len; i += 1024)            // OR: the last byte is shared with raw bits
-        atomicOr(reinterpret_cast<uint32_t *>(pkt + (i & ~3)), (uint32_t)a.prefix[i] << ((i & 3) * 8));
-    if (tid == 0) {
-        BitSink s;
-        s.init(pkt, total, 0);
-        s.put(a.header_bits, (int)a.header_nbits);
+    if (!fits) return;                                         // workgroup-uniform
+
+    // this workgroup's bit range [B0, B1) of the raw stream (workgroup 0 also owns the header)
+    const uint32_t B0 = blockIdx.x == 0 ? 0u : a.header_nbits + before;
+    const uint32_t B1 = a.header_nbits + before + local_total;
+    const uint32_t lbase = B0 & ~31u;                          // LDS word 0 <-> raw bit lbase
+    const uint32_t nwords = (B1 - lbase + 31) >> 5;
+    for (uint32_t w = tid; w < nwords + 1 && w < EP_WORDS; w += EP_THREADS) bits[w] = 0;
+    __syncthreads();
+
+    // (2) codes -> LDS
+    if (have) {
+        const uint32_t *rec = a.codes + ((size_t)f * n + i) * FFV2_CODES_PER_BP;
+        LdsBitSink s;
+        s.init(bits, a.header_nbits + before + wbase + (incl - mine) + tx - lbase);
+        const int c0 = (int)rec[0];
+        const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
+        put_golomb(s, mag);                                   // ffv2enc.c:148-150
+        if (c0) s.put(c0 < 0 ? 1u : 0u, 1);
+#pragma unroll 1
+        for (int b = 0; b < FFV2_NUM_BANDS; b++)
+            put_golomb(s, rec[1 + b]);                        // ffv2enc.c:174
         s.flush();
     }
-}
+    if (blockIdx.x == 0 && tid == 0)
+        atomicOr(&bits[0], a.header_bits);                    // raw header, bit 0 on (header_nbits <= 32)
+    __syncthreads();
 
-// One thread per block-plane: its 14 codes (+ sign) at its bit offset.
-__global__ __launch_bounds__(256) void ffv2_epack_kernel(const FFV2EStageArgs a)
-{
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.g.nblk) return;
-    const uint32_t total = a.sizes[f];
-    if (total == 0) return;
-    const uint32_t *rec = a.codes + ((size_t)f * a.g.nblk + i) * FFV2_CODES_PER_BP;
-    BitSink s;
-    s.init(a.packets + (size_t)f * a.packet_stride, total, a.bitoff[(size_t)f * a.g.nblk + i]);
-    const int c0 = (int)rec[0];
-    const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
-    put_golomb(s, mag);                                       // ffv2enc.c:148-150
-    if (c0) s.put(c0 < 0 ? 1u : 0u, 1);
-#pragma unroll 1
-    for (int b = 0; b < FFV2_NUM_BANDS; b++)
-        put_golomb(s, rec[1 + b]);                            // ffv2enc.c:174
-    s.flush();
+    // (3) LDS -> packet.  raw byte k sits at packet byte total-1-k.  Walk the aligned
+    // destination words that contain any of our raw bytes [ka, kb).
+    const uint32_t ka = B0 >> 3, kb = (B1 + 7) >> 3;           // raw bytes we contribute to
+    const uint32_t ea = (B0 + 7) >> 3, eb = B1 >> 3;           // raw bytes nobody else writes
+    if (kb > ka) {
+        const uint32_t dlo = (total - kb) & ~3u, dhi = (total - 1 - ka) & ~3u;
+        const uint8_t *lb = reinterpret_cast<const uint8_t *>(bits);
+        for (uint32_t d = dlo + 4 * tid; d <= dhi; d += 4 * EP_THREADS) {
+            uint32_t word = 0;
+            bool exclusive = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t k = (int64_t)total - 1 - (int64_t)(d + j);     // raw byte behind packet byte d+j
+                const bool ours = k >= (int64_t)ka && k < (int64_t)kb;
+                exclusive = exclusive && k >= (int64_t)ea && k < (int64_t)eb;
+                const uint32_t v = ours ? lb[(uint32_t)k - (lbase >> 3)] : 0u;
+                word |= v << (8 * j);
+            }
+            uint32_t *dst = reinterpret_cast<uint32_t *>(pkt + d);
+            if (exclusive) *dst = word;
+            else if (word) atomicOr(dst, word);
+        }
+    }
+    // range-coded prefix (data independent); its last byte is shared with raw bits -> OR
+    if (blockIdx.x == 0)
+        for (int k = tid; k < a.prefix_len; k += EP_THREADS)
+            atomicOr(reinterpret_cast<uint32_t *>(pkt + (k & ~3)), (uint32_t)a.prefix[k] << ((k & 3) * 8));
 }
 
 }  // namespace
@@ -625,9 +667,7 @@ hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
 
 hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(ffv2_escan_kernel, dim3(a.nframes), dim3(1024), 0, s, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ffv2_epack_kernel, dim3((a.g.nblk + 255) / 256, a.nframes), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ffv2_estage_kernel, dim3((a.g.nblk + EP_THREADS - 1) / EP_THREADS, a.nframes),
+                       dim3(EP_THREADS), 0, s, a);
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@ EXPORTS = [
     "ffv2amd_encode_frame", "ffv2amd_encode_batch_device", "ffv2amd_tstage_device",
     "ffv2amd_coded_gain", "ffv2amd_range_prefix",
     "ffv2amd_encoder_set_coef_sink", "ffv2amd_profile_enable", "ffv2amd_profile_read",
+    "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
 ]
@@ -25,7 +26,7 @@ class Info(C.Structure):
                 ("planes", C.c_int), ("depth", C.c_int),
                 ("num_sb_x", C.c_int), ("num_sb_y", C.c_int),
                 ("block_planes", C.c_int), ("max_batch", C.c_int),
-                ("packet_cap", C.c_size_t), ("tstage_bytes_per_frame", C.c_size_t),
+                ("packet_cap", C.c_size_t), ("packet_cap_qp", C.c_size_t), ("tstage_bytes_per_frame", C.c_size_t),
                 ("row_pitch", C.c_size_t), ("plane_stride", C.c_size_t), ("frame_stride", C.c_size_t)]
 
 
@@ -67,6 +68,10 @@ def load():
     lib.ffv2amd_encoder_set_coef_sink.argtypes = [C.c_void_p, C.c_void_p]
     lib.ffv2amd_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.ffv2amd_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.ffv2amd_encode_batch_to_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.ffv2amd_pvq_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p]
     lib.ffv2amd_coded_gain.argtypes = [C.c_int64]
     lib.ffv2amd_coded_gain.restype = C.c_uint32
     lib.ffv2amd_range_prefix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]

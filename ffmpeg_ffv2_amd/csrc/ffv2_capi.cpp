@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "gen/scan_lut.h"
@@ -145,6 +146,113 @@ int range_prefix(int pix_fmt, int num_sb, std::vector<uint8_t> &bytes, int *slac
     return 0;
 }
 
+// ------------------------------------------------------------------
+// Whole-packet entropy coder for qp > 0, host side (one serial chain per frame):
+// range coder above + the raw-bit tail (daala_entropy.c:227-270) + packet
+// assembly (daala_entropy.c:676-721).  The GPU delivers, per block-plane, the
+// "DC" slot, the 13 coded gains and the PVQ pulses; the symbol order is
+// ffv2enc.c:447-451 (header), :222,:197 (per superblock), :148-150,:174-186.
+// ------------------------------------------------------------------
+struct PacketEnc {
+    RangeEnc rc;
+    std::vector<uint8_t> raw;          // raw bytes in write order
+    uint64_t win = 0;
+    int nwin = 0;
+    bool abort_ = false;               // the reference would av_assert0 here
+
+    void bits(uint32_t v, int n)
+    {
+        if (nwin + n > 64) {
+            do { raw.push_back((uint8_t)win); win >>= 8; nwin -= 8; } while (nwin >= 8);
+        }
+        win |= (uint64_t)v << nwin;
+        nwin += n;
+    }
+    void golomb(uint32_t val)                                  // ffv2enc.c:105-123
+    {
+        const uint32_t v = val + 1;
+        if (val == 0) { bits(1, 1); return; }
+        const int nb = 31 - __builtin_clz(v);
+        for (int i = nb - 1; i >= 0; i--) bits(((v >> i) & 1) << 1, 2);
+        bits(1, 1);
+    }
+    // adaptive CDF symbol (daala_entropy.c:428-440 over :334-347)
+    void adapt(uint16_t *cdf, int n, int inc, int val)
+    {
+        if (val < 0 || val >= n) { abort_ = true; return; }      // :336
+        const uint32_t fl = val ? cdf[val - 1] : 0, fh = cdf[val], ft = cdf[n - 1];
+        if (!(fl < fh && fh <= ft && ft >= 2 && ft <= 32768)) { abort_ = true; return; }   // :340-343
+        const int sc = 15 - RangeEnc::ilog(ft - 1);
+        if ((ft << sc) > rc.rng) { abort_ = true; return; }      // :364
+        rc.encode(fl << sc, fh << sc, ft << sc);
+        if (cdf[n - 1] + inc > 32767)
+            for (int i = 0; i < n; i++) cdf[i] = (uint16_t)((cdf[i] >> 1) + i + 1);
+        for (int i = val; i < n; i++) cdf[i] = (uint16_t)(cdf[i] + inc);
+    }
+    int finish(uint8_t *out, size_t cap, size_t *size)
+    {
+        std::vector<uint8_t> head;
+        const int slack = rc.finish(head);
+        while (nwin > slack) { raw.push_back((uint8_t)win); win >>= 8; nwin -= 8; }
+        const size_t total = head.size() + raw.size();
+        if (total > cap) return FFV2AMD_ERR_NOSPACE;
+        memcpy(out, head.data(), head.size());
+        for (size_t i = 0; i < raw.size(); i++) out[total - 1 - i] = raw[i];
+        if (nwin > 0) {
+            if (head.empty()) return FFV2AMD_ERR_ABORT;          // :719
+            out[head.size() - 1] |= (uint8_t)win;
+        }
+        *size = total;
+        return 0;
+    }
+};
+
+const int BANDS_START[14] = { 0, 15, 23, 31, 63, 95, 127, 255, 383, 511, 1023, 1535, 2047, 4096 };
+
+int encode_frame_host_qp(const ffv2amd_info &in, int qp, const uint32_t *codes, const int16_t *y,
+                         uint8_t *out, size_t cap, size_t *size)
+{
+    PacketEnc e;
+    // header: ff_daalaent_encode_uint(pix_fmt, 196) then Exp-Golomb(qp)   (ffv2enc.c:447-451)
+    {
+        const uint32_t s = (uint32_t)in.pix_fmt >> 4;
+        auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
+        e.rc.encode(s ? q15(s) : 0, q15(s + 1), 32768);
+        e.bits((uint32_t)in.pix_fmt & 15u, 4);
+        e.golomb((uint32_t)qp);
+    }
+    uint16_t subdiv[4] = { 32, 64, 96, 128 };                    // daalaent_cdf_alloc(1,4,128,0,2,0)
+    std::vector<uint16_t> test((size_t)13 * qp);                  // daalaent_cdf_alloc(13,qp,64,0,6,0)
+    for (int r = 0; r < 13; r++)
+        for (int j = 0; j < qp; j++) test[(size_t)r * qp + j] = (uint16_t)(j + 1);
+    const int nsb = in.num_sb_x * in.num_sb_y;
+    for (int sb = 0; sb < nsb && !e.abort_; sb++) {
+        e.adapt(subdiv, 4, 128, 0);                               // split = END (ffv2enc.c:222)
+        e.bits(0, 4);                                             // tx type (ffv2enc.c:197)
+        for (int p = 0; p < in.planes && !e.abort_; p++) {
+            const size_t bp = (size_t)sb * in.planes + p;
+            const uint32_t *rec = codes + bp * FFV2_CODES_PER_BP;
+            const int16_t *yy = y + bp * FFV2_Y_STRIDE;
+            const int c0 = (int)rec[0];
+            e.golomb(c0 < 0 ? (uint32_t)(-(int64_t)c0) : (uint32_t)c0);
+            if (c0) e.bits(c0 < 0, 1);
+            for (int b = 0; b < 13 && !e.abort_; b++) {
+                e.golomb(rec[1 + b]);
+                const int lo = 1 + BANDS_START[b], len = BANDS_START[b + 1] - BANDS_START[b];
+                int pcnt = 0;
+                for (int j = 0; j < len && pcnt < qp && !e.abort_; j++) {   // ffv2enc.c:176-186
+                    const int q = yy[lo + j], aq = q < 0 ? -q : q;
+                    e.adapt(&test[(size_t)b * qp], qp, 64, aq);
+                    if (q) e.bits(q < 0, 1);
+                    pcnt += aq;
+                }
+            }
+        }
+    }
+    if (e.abort_) return FFV2AMD_ERR_ABORT;
+    return e.finish(out, cap, size);
+}
+
 int pixfmt_info(int pix_fmt, int *planes, int *depth)
 {
     switch (pix_fmt) {                    // allowed_pix_fmts, ffv2enc.c:596-601
@@ -182,6 +290,12 @@ struct ffv2amd_encoder {
     int32_t  *d_w1 = nullptr;
     uint8_t  *h_frame = nullptr, *h_pkt = nullptr;
     uint32_t *h_meta = nullptr;
+    // qp > 0 workspace (allocated on first use)
+    int32_t *d_coef_ws = nullptr;
+    int16_t *d_y = nullptr, *h_y = nullptr;
+    uint32_t *h_codes = nullptr;
+    uint8_t *d_pk_ws = nullptr;
+    uint32_t *d_sizes_ws = nullptr;
     // options
     int32_t *coef_sink = nullptr;
     bool profiling = false;
@@ -221,6 +335,9 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
+    (void)hipFree(e->d_coef_ws); (void)hipFree(e->d_y); (void)hipFree(e->d_pk_ws); (void)hipFree(e->d_sizes_ws);
+    if (e->h_y) (void)hipHostFree(e->h_y);
+    if (e->h_codes) (void)hipHostFree(e->h_codes);
     if (e->h_frame) (void)hipHostFree(e->h_frame);
     if (e->h_pkt) (void)hipHostFree(e->h_pkt);
     if (e->h_meta) (void)hipHostFree(e->h_meta);
@@ -269,6 +386,7 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     // worst case raw bits per block-plane: c0 (|c0| < 2^22: 43+1 bits) + 13 gains
     // (<= 2^15: 31 bits each) + 4 tx bits per superblock  -> < 58 bytes
     in.packet_cap = align_up((size_t)e->prefix_len + 16 + (size_t)in.block_planes * 58 + 64, 256);
+    in.packet_cap_qp = in.packet_cap + (size_t)in.block_planes * 2100;   // generous; NOSPACE if ever exceeded
 
     FFV2Geom &g = e->geom;
     g.width = width; g.height = height; g.depth = depth; g.planes = planes; g.bytes_per_sample = bps;
@@ -344,7 +462,8 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
         return FFV2AMD_ERR_INVAL;
     if (packet_stride & 3) return FFV2AMD_ERR_INVAL;
     if (qp < 0) return FFV2AMD_ERR_INVAL;
-    if (qp != 0) return FFV2AMD_ERR_UNSUPPORTED;              // PVQ path: SURVEY.md 8(f) rank 1
+    if (qp != 0) return FFV2AMD_ERR_UNSUPPORTED;              // packets of qp > 0 are finished on the host:
+                                                              // use ffv2amd_encode_batch_to_host
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
     int32_t *status = d_status ? d_status : e->d_status;
@@ -445,6 +564,16 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
         HIPCHK(hipMemcpyAsync(e->d_w1, W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, s));
         dW = e->d_w1;
     }
+    if (qp > 0) {
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t sz = 0;
+        int32_t st = 0;
+        int r2 = ffv2amd_encode_batch_to_host(e, 1, e->d_frame, qp, dW, out, out_cap, &sz, &st);
+        if (r2 < 0) return r2;
+        if (st < 0) return st;
+        *out_size = sz;
+        return FFV2AMD_OK;
+    }
     int r = ffv2amd_encode_batch_device(e, 1, e->d_frame, qp, dW, e->d_pkt, in.packet_cap,
                                         e->d_meta, (int32_t *)(e->d_meta + 1), s);
     if (r < 0) return r;
@@ -458,6 +587,81 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     if (n > out_cap) return FFV2AMD_ERR_NOSPACE;
     memcpy(out, e->h_pkt, n);
     *out_size = n;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, int N, int K,
+                              int count, int16_t *d_y, void *stream)
+{
+    if (!e || !d_X || !d_y || count < 1 || K < 0) return FFV2AMD_ERR_INVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(ffv2_launch_pvq_vectors(d_X, stride, N, K, count, d_y, (hipStream_t)stream));
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_frames,
+                                 int qp, const int32_t *d_W,
+                                 uint8_t *h_packets, size_t packet_stride,
+                                 uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !d_frames || !h_packets || !h_sizes || !h_status || nframes < 1 || nframes > e->info.max_batch || qp < 0)
+        return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t nb = (size_t)in.block_planes, B = (size_t)in.max_batch;
+    if (!e->d_pk_ws) {
+        HIPCHK(hipMalloc(&e->d_pk_ws, in.packet_cap * B));
+        HIPCHK(hipMalloc(&e->d_sizes_ws, sizeof(uint32_t) * B));
+    }
+    if (qp == 0) {
+        int r = ffv2amd_encode_batch_device(e, nframes, d_frames, 0, d_W, e->d_pk_ws, in.packet_cap,
+                                            e->d_sizes_ws, e->d_status, s);
+        if (r < 0) return r;
+        std::vector<uint8_t> tmp(in.packet_cap * (size_t)nframes);
+        HIPCHK(hipMemcpyAsync(h_sizes, e->d_sizes_ws, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_status, e->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tmp.data(), e->d_pk_ws, tmp.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int f = 0; f < nframes; f++) {
+            if (h_status[f] < 0) continue;
+            if (h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
+            memcpy(h_packets + (size_t)f * packet_stride, tmp.data() + (size_t)f * in.packet_cap, h_sizes[f]);
+        }
+        return FFV2AMD_OK;
+    }
+    // qp > 0: T-stage with coefficients kept, PVQ search, then the host range coder
+    if (!e->d_coef_ws) {
+        HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
+        HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
+        HIPCHK(hipHostMalloc(&e->h_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&e->h_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B, hipHostMallocDefault));
+    }
+    HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int32_t) * nframes, s));
+    FFV2TStageArgs a{};
+    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
+    a.coef = e->d_coef_ws; a.energy = nullptr; a.codes = e->d_codes; a.bitcnt = e->d_bitoff; a.W = d_W;
+    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan; a.status = e->d_status;
+    HIPCHK(ffv2_launch_tstage(a, s));
+    HIPCHK(ffv2_launch_pvq(e->d_coef_ws, d_W, e->d_y, qp, (long long)nb * nframes, s));
+    HIPCHK(hipMemcpyAsync(e->h_y, e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(e->h_codes, e->d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * nframes,
+                          hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_status, e->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<std::thread> pool;
+    for (int f = 0; f < nframes; f++) {
+        if (h_status[f] < 0) { h_sizes[f] = 0; continue; }
+        pool.emplace_back([=, &in]() {
+            size_t n = 0;
+            int r = encode_frame_host_qp(in, qp, e->h_codes + (size_t)f * nb * FFV2_CODES_PER_BP,
+                                         e->h_y + (size_t)f * nb * FFV2_Y_STRIDE,
+                                         h_packets + (size_t)f * packet_stride, packet_stride, &n);
+            h_status[f] = r;
+            h_sizes[f] = r < 0 ? 0 : (uint32_t)n;
+        });
+    }
+    for (auto &t : pool) t.join();
     return FFV2AMD_OK;
 }
 

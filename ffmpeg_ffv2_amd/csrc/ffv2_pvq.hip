@@ -1,0 +1,230 @@
+// ffv2_pvq.hip -- Q-stage for qp > 0: per-band gain normalisation and the greedy
+// pyramid-VQ pulse search (reference libavcodec/ffv2enc.c:163-171 calling
+// ff_pvq_search_exact_avx, libavcodec/x86/celt_pvq_search.asm:85-191,214-368,
+// INIT_XMM avx, USE_APPROXIMATION 0; horizontal sums libavutil/x86/x86util.asm:968-977).
+//
+// One wavefront per 64x64 block-plane walks its 13 bands.  Element i of a band
+// lives in lane i & 63; the asm's four XMM lanes are the classes i & 3.
+// What has to be reproduced for bit-exact pulses:
+//   * the three float sums (|x|, |x|*y, y*y) are accumulated per class from the LAST
+//     4-vector down to the first, then combined as (c0+c2)+(c1+c3): float addition is
+//     not associative, so those chains run sequentially (one lane per chain, LDS staging);
+//   * no fused multiply-add anywhere (built with -ffp-contract=off), IEEE divide, RNE rint;
+//   * per pulse: p = (|x|+Sxy)^2 / (y+Syy) per element; within a class the FIRST index
+//     with the strictly largest p wins; classes 2,3 beat 0,1 only when strictly larger;
+//     class 1 beats class 0 unless p1 < p0; the padding lanes of the last 4-vector take part.
+// PARITY UNPINNED with respect to the reference binary (no assembler here, no reference
+// vectors): pinned only against oracle/ffv2_oracle.c::ffv2o_pvq_search, which restates
+// the same asm independently.
+#include "ffv2_kernels.h"
+
+namespace {
+
+constexpr int PVQ_MAXN4 = 2052;               // band 12: 2049 coefficients -> 513 4-vectors
+
+struct PvqLds {
+    float ax[PVQ_MAXN4];                      // |x|, for broadcast reads of the chosen element
+    float fy[PVQ_MAXN4];                      // running pulse vector
+    float s1[PVQ_MAXN4];                      // staging for the sequential sums
+    float s2[PVQ_MAXN4];
+};
+
+// sum of class `cls` from the last 4-vector down to vector 0 (celt_pvq_search.asm:236-251)
+__device__ __forceinline__ float chain_desc(const float *a, int nv, int cls)
+{
+    float s = a[(nv - 1) * 4 + cls];
+    for (int v = nv - 2; v >= 0; v--) s = __fadd_rn(s, a[v * 4 + cls]);
+    return s;
+}
+
+__device__ __forceinline__ float hsum4(float c0, float c1, float c2, float c3)      // x86util.asm:968-977
+{
+    return __fadd_rn(__fadd_rn(c0, c2), __fadd_rn(c1, c3));
+}
+
+// M = elements per lane (ceil(N4 / 64)).  x[m] = normalised coefficient of element
+// i = lane + 64 m (0 beyond N).  Writes y[i] for i < N.
+template <int M>
+__device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, int lane, int16_t *yout)
+{
+    const int nv = (N + 3) >> 2, N4 = nv * 4;
+    float ax[M], fy[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = lane + 64 * m;
+        ax[m] = i < N ? fabsf(x[m]) : 0.0f;
+        if (i < N4) { L.ax[i] = ax[m]; L.s1[i] = ax[m]; }
+    }
+    __syncthreads();
+    float c = lane < 4 ? chain_desc(L.s1, nv, lane) : 0.0f;
+    const float Sx = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
+    __syncthreads();
+    if (Sx == 0.0f || Sx != Sx) {                             // comiss + jz: zero (or unordered) input
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int i = lane + 64 * m;
+            if (i < N) yout[i] = 0;
+        }
+        return;
+    }
+    const float b = __fdiv_rn((float)K, Sx);
+    int sy = 0;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = lane + 64 * m;
+        const int yt = __float2int_rn(__fmul_rn(b, ax[m]));   // cvtps2dq: round to nearest even
+        fy[m] = (float)yt;
+        sy += yt;
+        if (i < N4) {
+            L.fy[i] = fy[m];
+            L.s1[i] = __fmul_rn(ax[m], fy[m]);
+            L.s2[i] = __fmul_rn(fy[m], fy[m]);
+        }
+    }
+    __syncthreads();
+    c = lane < 4 ? chain_desc(L.s1, nv, lane) : (lane < 8 ? chain_desc(L.s2, nv, lane - 4) : 0.0f);
+    float Sxy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
+    float Syy = hsum4(__shfl(c, 4, 64), __shfl(c, 5, 64), __shfl(c, 6, 64), __shfl(c, 7, 64));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sy += __shfl_xor(sy, o, 64);   // integer: any order
+    int Kr = K - sy;
+    if (Kr != 0) {
+        const bool add = Kr > 0;
+        Syy = __fmul_rn(Syy, 0.5f);
+        for (int it = add ? Kr : -Kr; it > 0; it--) {
+            Syy = __fadd_rn(Syy, 0.5f);
+            // lanes start from their own first element with p = 0: if nothing is strictly
+            // better the class winner is its lowest index (the asm's initial max_idx)
+            float bp = lane < N4 ? 0.0f : -1.0f;
+            int bi = lane < N4 ? lane : 0x7fffffff;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int i = lane + 64 * m;
+                float num, den;
+                if (add) {
+                    den = __fadd_rn(fy[m], Syy);
+                    num = __fadd_rn(ax[m], Sxy);
+                } else {
+                    den = __fsub_rn(Syy, fy[m]);
+                    num = (0.0f < fy[m]) ? __fsub_rn(Sxy, ax[m]) : 0.0f;
+                }
+                const float pp = __fdiv_rn(__fmul_rn(num, num), den);
+                if (i < N4 && bp < pp) { bp = pp; bi = i; }
+            }
+            // same class across lanes (lane ^ 4, 8, 16, 32): larger p, then lower index
+#pragma unroll
+            for (int o = 4; o <= 32; o <<= 1) {
+                const float op = __shfl_xor(bp, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
+            }
+            {   // classes (3,2) replace (1,0) only when strictly greater
+                const float op = __shfl_xor(bp, 2, 64);
+                const int oi = __shfl_xor(bi, 2, 64);
+                if ((lane & 2) == 0 && bp < op) { bp = op; bi = oi; }
+            }
+            // class 1 replaces class 0 unless p1 < p0 (cmpss predicate 5 = NLT)
+            const float p1 = __shfl(bp, 1, 64), p0 = __shfl(bp, 0, 64);
+            const int i1 = __shfl(bi, 1, 64), i0 = __shfl(bi, 0, 64);
+            const int best = !(p1 < p0) ? i1 : i0;
+            const float axb = L.ax[best], fyb = L.fy[best];
+            if (add) { Sxy = __fadd_rn(Sxy, axb); Syy = __fadd_rn(Syy, fyb); }
+            else     { Sxy = __fsub_rn(Sxy, axb); Syy = __fsub_rn(Syy, fyb); }
+            const float nf = add ? __fadd_rn(fyb, 1.0f) : __fsub_rn(fyb, 1.0f);
+#pragma unroll
+            for (int m = 0; m < M; m++)
+                if (lane + 64 * m == best) fy[m] = nf;
+            __syncthreads();
+            if (lane == 0) L.fy[best] = nf;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = lane + 64 * m;
+        if (i < N) {
+            const int iv = __float2int_rn(fy[m]);
+            yout[i] = (int16_t)(signbit(x[m]) ? -iv : iv);    // orps sign, cvtps2dq
+        }
+    }
+    __syncthreads();
+}
+
+// bands in coding order (ffv2.c:100-120): band b = coefficients [1+BS[b], 1+BS[b+1])
+__device__ constexpr int PVQ_BS[14] = { 0, 15, 23, 31, 63, 95, 127, 255, 383, 511, 1023, 1535, 2047, 4096 };
+
+template <int M>
+__device__ __forceinline__ void quant_band(const int32_t *coef, int b, int32_t W, int K, PvqLds &L, int lane, int16_t *y)
+{
+    const int lo = 1 + PVQ_BS[b];
+    const int N = PVQ_BS[b + 1] - PVQ_BS[b];                   // 2049 for the last band: it also
+    int cv[M];                                                 // reads temp2[4096]
+    long long e = 0;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = lane + 64 * m;
+        cv[m] = i < N ? (lo + i < 4096 ? coef[lo + i] : W) : 0;
+        e += (long long)cv[m] * cv[m];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) e += __shfl_xor(e, o, 64);
+    const float fgain = __fadd_rn(sqrtf((float)e), 1.1920929e-7f);     // ffv2enc.c:166
+    float x[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) x[m] = __fdiv_rn((float)cv[m], fgain);  // ffv2enc.c:169
+    pvq_search_wave<M>(x, N, K, L, lane, y + lo);
+}
+
+struct FFV2PvqArgs {
+    const int32_t *coef;      // [nbp][4096] coding order
+    const int32_t *W;         // [nbp] or null
+    int16_t *y;               // [nbp][FFV2_Y_STRIDE]; element 1+j of the coding order at y[1+j], W slot at y[4096]
+    int qp;
+    long long nbp;
+};
+
+__global__ __launch_bounds__(64) void ffv2_pvq_kernel(const FFV2PvqArgs a)
+{
+    __shared__ PvqLds L;
+    const long long bp = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int32_t *coef = a.coef + bp * 4096;
+    const int32_t W = a.W ? a.W[bp] : 0;
+    int16_t *y = a.y + bp * FFV2_Y_STRIDE;
+    for (int b = 0; b < 6; b++)  quant_band<1>(coef, b, W, a.qp, L, lane, y);
+    for (int b = 6; b < 9; b++)  quant_band<2>(coef, b, W, a.qp, L, lane, y);
+    for (int b = 9; b < 12; b++) quant_band<8>(coef, b, W, a.qp, L, lane, y);
+    quant_band<33>(coef, 12, W, a.qp, L, lane, y);
+}
+
+// test hook: the bare search on caller-provided float vectors
+__global__ __launch_bounds__(64) void ffv2_pvq_vectors_kernel(const float *X, int stride, int N, int K, int16_t *y)
+{
+    __shared__ PvqLds L;
+    const int lane = threadIdx.x;
+    const float *xv = X + (size_t)blockIdx.x * stride;
+    int16_t *yv = y + (size_t)blockIdx.x * stride;
+    float x[33];
+#pragma unroll
+    for (int m = 0; m < 33; m++) {
+        const int i = lane + 64 * m;
+        x[m] = i < N ? xv[i] : 0.0f;
+    }
+    pvq_search_wave<33>(x, N, K, L, lane, yv);
+}
+
+}  // namespace
+
+hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s)
+{
+    FFV2PvqArgs a{ coef, W, y, qp, nbp };
+    hipLaunchKernelGGL(ffv2_pvq_kernel, dim3((unsigned)nbp), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ffv2_launch_pvq_vectors(const float *X, int stride, int N, int K, int count, int16_t *y, hipStream_t s)
+{
+    if (N < 1 || N > 2049 || stride < N) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ffv2_pvq_vectors_kernel, dim3(count), dim3(64), 0, s, X, stride, N, K, y);
+    return hipGetLastError();
+}

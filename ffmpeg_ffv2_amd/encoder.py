@@ -56,7 +56,7 @@ class FFV2Encoder:
         for p in range(i.planes):
             data[p] = frame[p].ctypes.data
             ls[p] = frame[p].strides[0]
-        out = np.empty(i.packet_cap, np.uint8)
+        out = np.empty(i.packet_cap if qp == 0 else i.packet_cap_qp, np.uint8)
         n = C.c_size_t(0)
         wp = None
         if W is not None:
@@ -124,6 +124,38 @@ class FFV2Encoder:
             pk.data_ptr(), pk.stride(0), sizes.data_ptr(), status.data_ptr(), C.c_void_p(stream)),
             "ffv2amd_encode_batch_device")
         return pk, sizes, status
+
+    def encode_batch_to_host(self, d_frames, qp=0, d_W=None):
+        """Synchronous batch encode2 for any qp >= 0: frames in HBM -> list of packets (bytes);
+        a frame the reference would abort on raises FFV2Error(-1)."""
+        F = d_frames.shape[0]
+        cap = self.info.packet_cap if qp == 0 else self.info.packet_cap_qp
+        pk = np.empty((F, cap), np.uint8)
+        sizes = np.zeros(F, np.uint32)
+        status = np.zeros(F, np.int32)
+        _lib.check(self._lib.ffv2amd_encode_batch_to_host(
+            self._h, F, d_frames.data_ptr(), qp, d_W.data_ptr() if d_W is not None else None,
+            pk.ctypes.data_as(C.c_void_p), cap, sizes.ctypes.data_as(C.c_void_p),
+            status.ctypes.data_as(C.c_void_p)), "ffv2amd_encode_batch_to_host")
+        for f in range(F):
+            if status[f] < 0:
+                raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
+        return [pk[f, : sizes[f]].tobytes() for f in range(F)]
+
+    def pvq_search(self, X, K):
+        """Device PVQ search on rows of X (count, N) float32 -> int16 pulses (count, N)."""
+        import torch
+        X = np.ascontiguousarray(X, np.float32)
+        count, N = X.shape
+        stride = N + 8
+        Xp = np.zeros((count, stride), np.float32)
+        Xp[:, :N] = X
+        dX = torch.from_numpy(Xp).to("cuda:%d" % self.device)
+        dy = torch.zeros((count, stride), dtype=torch.int16, device=dX.device)
+        stream = torch.cuda.current_stream(dX.device).cuda_stream
+        _lib.check(self._lib.ffv2amd_pvq_search_device(self._h, dX.data_ptr(), stride, N, K, count,
+                                                       dy.data_ptr(), C.c_void_p(stream)), "pvq_search_device")
+        return dy.cpu().numpy()[:, :N].astype(np.int32)
 
     def set_coef_sink(self, d_coef):
         """Also keep the coding-order coefficients of every batch encode in HBM

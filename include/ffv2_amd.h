@@ -54,6 +54,7 @@ typedef struct ffv2amd_info {
     int block_planes;              /* num_sb_x*num_sb_y*planes: 64x64 blocks per frame     */
     int max_batch;                 /* frames one *_device call may carry                   */
     size_t packet_cap;             /* upper bound of one packet in bytes (qp == 0)         */
+    size_t packet_cap_qp;          /* upper bound for any qp (host-assembled packets)      */
     size_t tstage_bytes_per_frame; /* algorithmic HBM bytes of the T-stage, SURVEY.md 8(d):
                                       P*W*H*bytes_in + P*(64nsx)*(64nsy)*4                 */
     /* layout the *_device entry points expect for frames resident in HBM */
@@ -99,6 +100,25 @@ int  ffv2amd_encode_batch_device(ffv2amd_encoder *enc, int nframes, const void *
  * Used by the parity tests and the roofline measurement. */
 int  ffv2amd_tstage_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,
                            int32_t *d_coef, int64_t *d_energy, void *stream);
+
+/* Batch variant of encode2 that ends in host memory and accepts any qp >= 0
+ * (synchronous).  Frames are resident in HBM (layout of ffv2amd_info); packets are
+ * written to h_packets[f*packet_stride ...], h_sizes[f], h_status[f].
+ * qp == 0 : everything on the GPU, packets copied back.
+ * qp  > 0 : T-stage and PVQ search (ffv2enc.c:163-171, celt_pvq_search.asm) on the GPU;
+ *           the adaptive range coder (daala_entropy.c:328-379,428-440), which is one
+ *           serial chain per frame, runs on host threads, one frame per thread.
+ * A frame on which the reference would abort (daala_entropy.c:336,342: a band whose
+ * pulses all land on one coefficient, or qp == 1) gets status FFV2AMD_ERR_ABORT. */
+int  ffv2amd_encode_batch_to_host(ffv2amd_encoder *enc, int nframes, const void *d_frames,
+                                  int qp, const int32_t *d_W,
+                                  uint8_t *h_packets, size_t packet_stride,
+                                  uint32_t *h_sizes, int32_t *h_status);
+
+/* Test hook: the device PVQ search on `count` float vectors of N <= 2049 elements
+ * (d_X[v*stride + i]); writes int16 pulses to d_y[v*stride + i]. */
+int  ffv2amd_pvq_search_device(ffv2amd_encoder *enc, const float *d_X, int stride, int N, int K,
+                               int count, int16_t *d_y, void *stream);
 
 /* Optional: also materialise the coding-order coefficients of every batch encode
  * in HBM (what the reference keeps in temp2[], ffv2enc.c:194,201, and what the

@@ -155,12 +155,83 @@ def test_sample_out_of_range_is_an_error():
     enc.close()
 
 
-def test_qp_nonzero_is_refused_not_approximated():
+def test_batch_device_refuses_qp_nonzero():
+    """The all-device batch call is the qp=0 path; qp>0 packets are finished on the host."""
     from ffmpeg_ffv2_amd import FFV2Error
     enc = _enc(64, 64, "gray")
     with pytest.raises(FFV2Error) as e:
-        enc.encode2(np.zeros((1, 64, 64), np.uint8), qp=16)
+        enc.encode_batch_device(enc.upload(np.zeros((1, 1, 64, 64), np.uint8)), qp=16)
     assert e.value.code == -38
+    enc.close()
+
+
+# ---- qp > 0: PARITY UNPINNED against the reference binary (no assembler for
+# celt_pvq_search.asm, no reference vectors); these compare the HIP path with the
+# oracle's independent restatement of the same asm. ----
+@pytest.mark.parametrize("N", [8, 15, 32, 128, 512, 2049, 5, 33, 1000])
+@pytest.mark.parametrize("K", [1, 4, 16, 64])
+def test_pvq_search_matches_oracle(oracle, N, K):
+    enc = _enc(64, 64, "gray")
+    rng = np.random.default_rng(1000 * N + K)
+    X = rng.standard_normal((24, N)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True) + 1e-9
+    X[1] = 0                                               # zero-input shortcut
+    X[2] = 0; X[2, N // 2] = -1.0                          # one spike: all pulses on one element
+    X[3, N // 3:] = 0                                      # sparse tail
+    X[4] = np.abs(X[4])                                    # ties in sign handling
+    X[5] = np.round(X[5] * 4) / 4                          # many exact ties in p
+    X[6] = 1.0 / np.sqrt(N)                                # all equal: pure tie-break order
+    X[7] = rng.laplace(size=N).astype(np.float32) * 0.05
+    got = enc.pvq_search(X, K)
+    for v in range(X.shape[0]):
+        want = oracle.pvq_search(X[v], K)
+        assert np.array_equal(got[v], want), "vector %d N=%d K=%d: first diff at %s" % (
+            v, N, K, np.flatnonzero(got[v] != want)[:4])
+    enc.close()
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", [("gray", 1, 64, 64, 8), ("yuv444p", 3, 100, 150, 8),
+                                             ("yuv444p10le", 3, 128, 192, 10)])
+@pytest.mark.parametrize("qp", [4, 16, 64])
+def test_packets_qp_nonzero_noise(oracle, fmt, P, H, W, depth, qp):
+    enc = _enc(W, H, fmt, max_batch=2)
+    fr = np.stack([synth.noise(n, P, H, W, depth) for n in range(2)])
+    want = [oracle.encode(fr[n], fmt, qp=qp) for n in range(2)]
+    assert enc.encode2(fr[0], qp=qp) == want[0]            # host boundary (encode2)
+    assert enc.encode_batch_to_host(enc.upload(fr), qp=qp) == want
+    wv = np.random.default_rng(qp).integers(-40, 40, (2, enc.info.block_planes)).astype(np.int32)
+    import torch
+    got = enc.encode_batch_to_host(enc.upload(fr), qp=qp, d_W=torch.from_numpy(wv).cuda())
+    assert got == [oracle.encode(fr[n], fmt, qp=qp, W=wv[n]) for n in range(2)]
+    enc.close()
+
+
+def test_qp_abort_conditions_mirror_the_reference(oracle):
+    """daala_entropy.c:336,342: qp == 1 always aborts; a band whose pulses all land on one
+    coefficient aborts (any flat or structured picture).  Both sides must say so."""
+    from ffmpeg_ffv2_amd import FFV2Error
+    enc = _enc(64, 64, "gray")
+    noise = synth.noise(0, 1, 64, 64, 8)
+    flat = np.full((1, 64, 64), 200, np.uint8)
+    for frame, qp in ((noise, 1), (flat, 4)):
+        with pytest.raises(RuntimeError):
+            oracle.encode(frame, "gray", qp=qp)
+        with pytest.raises(FFV2Error) as e:
+            enc.encode2(frame, qp=qp)
+        assert e.value.code == -1
+    # structured content: whatever the oracle does (packet or abort), the HIP path does too
+    for n, qp in ((0, 16), (1, 4), (2, 64), (3, 2)):
+        frame = synth.structured(n, 1, 64, 64, 8)
+        try:
+            want = oracle.encode(frame, "gray", qp=qp)
+        except RuntimeError:
+            want = None
+        try:
+            got = enc.encode2(frame, qp=qp)
+        except FFV2Error as e:
+            assert e.code == -1
+            got = None
+        assert got == want, "structured frame %d qp %d" % (n, qp)
     enc.close()
 
 

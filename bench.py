@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--no-coef", action="store_true", help="do not materialise coefficients (fused qp=0 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--qp", type=int, default=0,
+                    help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +91,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.qp > 0:
+        # not the headline metric: synchronous, packets finished on host threads
+        for _ in range(args.warmup):
+            pk = enc.encode_batch_to_host(d_frames, qp=args.qp)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pk = enc.encode_batch_to_host(d_frames, qp=args.qp)
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "Mpix/s encode, qp=%d (informational)" % args.qp,
+                              "value": round(world * F * args.steps * W * H / dt / 1e6, 1), "unit": "Mpix/s",
+                              "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "packet_bytes_frame0": len(pk[0]), "config": {"workload": "%dx%d %s qp=%d" % (W, H, fmt, args.qp)}}))
+        enc.close()
+        return
     for _ in range(args.warmup):
         enc.encode_batch_device(d_frames, out=out, stream=stream)
     barrier()

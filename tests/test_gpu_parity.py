@@ -117,6 +117,55 @@ def test_full_size_frame_bit_exact(oracle, fmt, P, H, W, depth, kind):
     enc.close()
 
 
+@pytest.mark.parametrize("fmt,P,H,W,depth,kind", [
+    ("yuv444p", 3, 2160, 3840, 8, "S2"),          # BASELINE config 4 frame size
+    ("yuv444p12le", 3, 4320, 7680, 12, "S1"),     # BASELINE config 5 frame size
+])
+def test_full_size_frame_bit_exact_c4_c5(oracle, fmt, P, H, W, depth, kind):
+    enc = _enc(W, H, fmt)
+    fr = synth.make(kind, 1, P, H, W, depth)
+    assert enc.encode2(fr) == oracle.encode(fr, fmt)
+    enc.close()
+
+
+def test_random_geometries(oracle):
+    """Property test over ragged sizes / formats / content: packets equal the oracle's."""
+    rng = np.random.default_rng(2026)
+    fmts = [("gray", 1, 8), ("yuv444p", 3, 8), ("gbrp", 3, 8), ("yuv444p10le", 3, 10),
+            ("gbrp10le", 3, 10), ("yuv444p12le", 3, 12), ("gbrp12le", 3, 12)]
+    for trial in range(40):
+        fmt, P, depth = fmts[rng.integers(len(fmts))]
+        W = int(rng.integers(1, 400)); H = int(rng.integers(1, 300))
+        enc = _enc(W, H, fmt)
+        kind = rng.integers(4)
+        if kind == 0:
+            fr = rng.integers(0, 1 << depth, (P, H, W))
+        elif kind == 1:
+            fr = synth.structured(trial, P, H, W, depth).astype(np.int64)
+        elif kind == 2:                                   # max-contrast checkerboard / stripes
+            y, x = np.mgrid[0:H, 0:W]
+            fr = np.stack([(((x // (p + 1) + y // (trial % 3 + 1)) & 1) * ((1 << depth) - 1)) for p in range(P)])
+        else:                                             # sparse impulses on flat ground
+            fr = np.full((P, H, W), (1 << depth) // 3)
+            idx = rng.integers(0, P * H * W, 20)
+            fr.reshape(-1)[idx] = rng.integers(0, 1 << depth, 20)
+        fr = fr.astype(synth.dtype_for(depth))
+        wv = None
+        if trial % 3 == 0:
+            wv = rng.integers(-2000, 2000, enc.info.block_planes).astype(np.int32)
+        assert enc.encode2(fr, W=wv) == oracle.encode(fr, fmt, W=wv), (trial, fmt, W, H, kind)
+        enc.close()
+
+
+def test_gain_table_overflow_is_an_error():
+    from ffmpeg_ffv2_amd import FFV2Error
+    enc = _enc(64, 64, "gray")
+    with pytest.raises(FFV2Error) as e:                    # |W| = 2^30: band-12 gain far beyond the table
+        enc.encode2(np.zeros((1, 64, 64), np.uint8), W=[1 << 30])
+    assert e.value.code == -34
+    enc.close()
+
+
 def test_full_size_properties_8k12():
     """BASELINE config 5 size: properties that need no oracle run.
     * determinism, * frame independence inside a batch (ffv2enc.c:461-469: no

@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--frames-per-step", type=int, default=8)
     ap.add_argument("--no-coef", action="store_true", help="do not materialise coefficients (fused qp=0 path)")

@@ -88,6 +88,26 @@ def test_survey_known_answers():
     enc.close()
 
 
+def test_c1_golden_packets_and_determinism():
+    """BASELINE config 1 through the HIP path against committed digests (no oracle call), as one
+    30-frame batch, repeated: the packets must not change from run to run (atomics, LDS hand-offs)."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c1_packets.json")))["packets"]
+    enc = _enc(320, 240, "yuv444p", max_batch=30)
+    fr = np.stack([synth.make(e["kind"], e["frame"], 3, 240, 320, 8) for e in gold])
+    d = enc.upload(fr)
+    first = None
+    for rep in range(10):
+        pk = enc.collect(*enc.encode_batch_device(d))
+        if first is None:
+            first = pk
+            for e, b in zip(gold, pk):
+                assert (len(b), hashlib.md5(b).hexdigest()) == (e["bytes"], e["md5"]), e["frame"]
+        else:
+            assert pk == first, "run %d differs" % rep
+    enc.close()
+
+
 def test_batch_device_api_with_phantom_w(oracle):
     import torch
     W, H, fmt, P, depth, F = 320, 240, "yuv444p", 3, 8, 6

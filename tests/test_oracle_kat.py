@@ -102,3 +102,15 @@ def test_rejected_pix_fmt(oracle):
     # yuv420p (0) and friends are not in allowed_pix_fmts (ffv2enc.c:596-601)
     assert oracle.lib.ffv2o_pixfmt_info(0, None, None) < 0
     assert oracle.lib.ffv2o_pixfmt_info(5, None, None) == 0
+
+
+def test_c1_plumbing_golden(oracle):
+    """BASELINE config 1 (CPU-runnable plumbing case): 30 frames 320x240, digests committed in
+    tests/golden/c1_packets.json (tools/make_c1_golden.py)."""
+    import json
+    from ffmpeg_ffv2_amd import frames as synth
+    gold = json.load(open(os.path.join(GOLD, "c1_packets.json")))["packets"]
+    assert len(gold) == 30
+    for e in gold:
+        pk = oracle.encode(synth.make(e["kind"], e["frame"], 3, 240, 320, 8), "yuv444p")
+        assert (len(pk), md5(pk)) == (e["bytes"], e["md5"]), e["frame"]

@@ -295,6 +295,7 @@ struct ffv2amd_encoder {
     int16_t *d_y = nullptr, *h_y = nullptr;
     uint32_t *h_codes = nullptr;
     uint8_t *d_pk_ws = nullptr;
+    int32_t *d_inv_plane = nullptr;
     uint32_t *d_sizes_ws = nullptr;
     // options
     int32_t *coef_sink = nullptr;
@@ -335,6 +336,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
+    (void)hipFree(e->d_inv_plane);
     (void)hipFree(e->d_coef_ws); (void)hipFree(e->d_y); (void)hipFree(e->d_pk_ws); (void)hipFree(e->d_sizes_ws);
     if (e->h_y) (void)hipHostFree(e->h_y);
     if (e->h_codes) (void)hipHostFree(e->h_codes);
@@ -587,6 +589,19 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     if (n > out_cap) return FFV2AMD_ERR_NOSPACE;
     memcpy(out, e->h_pkt, n);
     *out_size = n;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t *d_coef,
+                                  void *d_frames_out, void *stream)
+{
+    if (!e || !d_coef || !d_frames_out || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
+    HIPCHK(hipSetDevice(e->device));
+    const FFV2Geom &g = e->geom;
+    if (!e->d_inv_plane)
+        HIPCHK(hipMalloc(&e->d_inv_plane, sizeof(int32_t) * (size_t)g.nsx * 64 * g.nsy * 64 * g.planes * e->info.max_batch));
+    HIPCHK(ffv2_launch_inverse(g, nframes, d_coef, e->d_inv_plane, (uint8_t *)d_frames_out, e->d_lds_scan,
+                               (hipStream_t)stream));
     return FFV2AMD_OK;
 }
 

@@ -50,6 +50,8 @@ struct FFV2EStageArgs {
 #define FFV2_Y_STRIDE 4104        // int16 per block-plane of the PVQ output (4096 + phantom slot, padded)
 
 hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s);
+hipError_t ffv2_launch_inverse(const FFV2Geom &g, int nframes, const int32_t *coef, int32_t *plane,
+                               uint8_t *frames, const uint16_t *lds_scan, hipStream_t s);
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s);
 hipError_t ffv2_launch_pvq_vectors(const float *X, int stride, int N, int K, int count, int16_t *y, hipStream_t s);
 hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s);

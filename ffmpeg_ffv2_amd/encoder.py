@@ -142,6 +142,29 @@ class FFV2Encoder:
                 raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
         return [pk[f, : sizes[f]].tobytes() for f in range(F)]
 
+    def inverse_tstage(self, d_coef):
+        """Decoder-side inverse of the T-stage: torch int32 (F, block_planes, 4096) ->
+        torch uint8 (F, frame_stride) in the device frame layout."""
+        import torch
+        F = d_coef.shape[0]
+        out = torch.zeros((F, self.info.frame_stride), dtype=torch.uint8, device=d_coef.device)
+        stream = torch.cuda.current_stream(d_coef.device).cuda_stream
+        _lib.check(self._lib.ffv2amd_inverse_tstage_device(self._h, F, d_coef.data_ptr(), out.data_ptr(),
+                                                           C.c_void_p(stream)), "inverse_tstage_device")
+        return out
+
+    def unpack_frames(self, buf):
+        """Inverse of pack_frames: (F, frame_stride) uint8 host array -> (F,P,H,W) samples."""
+        i = self.info
+        buf = np.ascontiguousarray(buf, np.uint8)
+        F = buf.shape[0]
+        bps = self.dtype.itemsize
+        out = np.empty((F, i.planes, i.height, i.width * bps), np.uint8)
+        for p in range(i.planes):
+            v = buf[:, p * i.plane_stride: p * i.plane_stride + i.row_pitch * i.height].reshape(F, i.height, i.row_pitch)
+            out[:, p] = v[:, :, : i.width * bps]
+        return out.view(self.dtype).reshape(F, i.planes, i.height, i.width)
+
     def pvq_search(self, X, K):
         """Device PVQ search on rows of X (count, N) float32 -> int16 pulses (count, N)."""
         import torch

@@ -115,6 +115,14 @@ int  ffv2amd_encode_batch_to_host(ffv2amd_encoder *enc, int nframes, const void 
                                   uint8_t *h_packets, size_t packet_stride,
                                   uint32_t *h_sizes, int32_t *h_status);
 
+/* Decoder-side inverse of the T-stage (reference ffv2.c:81-98 coding_to_raster, :4962-4972
+ * tx_inv_2d / od_bin_idct64, :216-239 lapping post-filter in ffv2dec.c's seam order,
+ * :40-52 coeffs_2_ref): coding-order coefficients d_coef[nframes][block_planes][4096] ->
+ * pictures d_frames_out in the layout of ffv2amd_info.  A round-trip self check for the
+ * encoder (on picture data inverse(tstage(x)) == x exactly), not a decoder. */
+int  ffv2amd_inverse_tstage_device(ffv2amd_encoder *enc, int nframes, const int32_t *d_coef,
+                                   void *d_frames_out, void *stream);
+
 /* Test hook: the device PVQ search on `count` float vectors of N <= 2049 elements
  * (d_X[v*stride + i]); writes int16 pulses to d_y[v*stride + i]. */
 int  ffv2amd_pvq_search_device(ffv2amd_encoder *enc, const float *d_X, int stride, int N, int K,

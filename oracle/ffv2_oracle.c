@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "gen/fdct64_ir_table.h"
+#include "gen/idct64_ir_table.h"
 #include "gen/scan_lut.h"
 
 #define SB 64
@@ -54,13 +55,10 @@ static inline int32_t wmul_add(int32_t a, int32_t k, int32_t r)
 /* (libavcodec/ffv2.c:4678-4812 od_bin_fdct64 and the OD_F* macro tree */
 /*  :313-4001; op semantics in oracle/gen/fdct64_ir_table.h)           */
 /* ------------------------------------------------------------------ */
-void ffv2o_fdct64(int32_t y[64], const int32_t *x, int xstride)
+static void run_ir(const int32_t (*ops)[6], int nops, int32_t *r)
 {
-    int32_t r[FDCT64_IR_NREGS];
-    for (int k = 0; k < 64; k++)
-        r[k] = x[k * xstride];
-    for (int i = 0; i < FDCT64_IR_NOPS; i++) {
-        const int32_t *op = FDCT64_IR_OPS[i];
+    for (int i = 0; i < nops; i++) {
+        const int32_t *op = ops[i];
         int32_t a = r[op[2]];
         switch (op[0]) {
         case 0: r[op[1]] = (int32_t)((uint32_t)a - (uint32_t)r[op[3]]); break;
@@ -71,8 +69,28 @@ void ffv2o_fdct64(int32_t y[64], const int32_t *x, int xstride)
         case 5: r[op[1]] = (int32_t)(0u - (uint32_t)a); break;
         }
     }
+}
+
+void ffv2o_fdct64(int32_t y[64], const int32_t *x, int xstride)
+{
+    int32_t r[FDCT64_IR_NREGS];
+    for (int k = 0; k < 64; k++)
+        r[k] = x[k * xstride];
+    run_ir(FDCT64_IR_OPS, FDCT64_IR_NOPS, r);
     for (int k = 0; k < 64; k++)
         y[k] = r[FDCT64_IR_OUT[k]];
+}
+
+/* 1-D 64-point inverse (libavcodec/ffv2.c:4814-4948 od_bin_idct64 over the OD_I* macros):
+ * decoder side, SURVEY.md section 8(f) rank 2. */
+void ffv2o_idct64(int32_t *x, int xstride, const int32_t y[64])
+{
+    int32_t r[IDCT64_IR_NREGS];
+    for (int k = 0; k < 64; k++)
+        r[k] = y[k];
+    run_ir(IDCT64_IR_OPS, IDCT64_IR_NOPS, r);
+    for (int k = 0; k < 64; k++)
+        x[k * xstride] = r[IDCT64_IR_OUT[k]];
 }
 
 /* ------------------------------------------------------------------ */
@@ -221,6 +239,91 @@ int ffv2o_tstage(const uint8_t *const data[4], const ptrdiff_t linesize[4],
                     }
             }
     oframe_free(&f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* decoder-side inverse of the T-stage (round-trip self check)         */
+/* ------------------------------------------------------------------ */
+/* lapping post-filter, 32 taps, in place (libavcodec/ffv2.c:216-239; note the
+ * truncating per-sample divide of :229-230, which makes it only approximately the
+ * inverse of the pre-filter) */
+void ffv2o_inv_lap_filter32(int32_t x[32])
+{
+    int32_t t[32];
+    for (int i = 0; i < 16; i++)
+        t[31 - i] = x[i] - x[31 - i];
+    for (int i = 0; i < 16; i++)
+        t[15 - i] = x[15 - i] - (t[16 + i] >> 1);
+    for (int i = 16; i < 31; i++) {
+        t[i]     -= wmul_add(t[i + 1], LAP32_P[i + 15], 32) >> 6;
+        t[i + 1] -= wmul_add(t[i], LAP32_P[i], 32) >> 6;
+    }
+    for (int i = 31; i >= 16; i--)
+        t[i] = (int32_t)((uint32_t)t[i] << 6) / LAP32_P[i - 16];
+    for (int i = 0; i < 16; i++) {
+        t[i] += t[31 - i] >> 1;
+        x[i] = t[i];
+    }
+    for (int i = 16; i < 32; i++)
+        x[i] = t[31 - i] - t[i];
+}
+
+/* coefficients in coding order [nsb*planes][4096] -> picture planes:
+ * coding_to_raster (ffv2.c:81-98), tx_inv_2d (ffv2.c:4962-4972: rows first, into columns
+ * of tmp, then columns), post-filters on all horizontal seams then on all vertical seams
+ * (ffv2dec.c, DOLAP block), coeffs_2_ref (ffv2.c:40-52; no clipping). The debugging
+ * overlay of ffv2dec.c:258-273 is not part of the transform and is left out. */
+int ffv2o_inverse_tstage(const int32_t *coef, int width, int height, int pix_fmt,
+                         uint8_t *const data[4], const ptrdiff_t linesize[4])
+{
+    int planes, depth;
+    if (ffv2o_pixfmt_info(pix_fmt, &planes, &depth) < 0 || width <= 0 || height <= 0)
+        return FFV2O_ERR_PIXFMT;
+    const int nsx = (width + SB - 1) / SB, nsy = (height + SB - 1) / SB;
+    const int gw = nsx * SB, gh = nsy * SB;
+    int32_t *pl = malloc((size_t)gw * gh * sizeof(int32_t));
+    if (!pl)
+        return FFV2O_ERR_NOMEM;
+    for (int p = 0; p < planes; p++) {
+        for (int sby = 0; sby < nsy; sby++)
+            for (int sbx = 0; sbx < nsx; sbx++) {
+                const int32_t *c = coef + (((size_t)sby * nsx + sbx) * planes + p) * 4096;
+                int32_t src[4096], tmp[4096];
+                int32_t *dst = pl + (size_t)sby * SB * gw + sbx * SB;
+                for (int q = 0; q < 4096; q++)
+                    src[FFV2_SCAN_LUT[q]] = c[q];
+                for (int i = 0; i < 64; i++)
+                    ffv2o_idct64(tmp + i, 64, src + 64 * i);
+                for (int i = 0; i < 64; i++)
+                    ffv2o_idct64(dst + i, gw, tmp + 64 * i);
+            }
+        for (int j = 1; j < nsy; j++)
+            for (int xx = 0; xx < gw; xx++) {
+                int32_t col[32];
+                int32_t *s = pl + (size_t)(j * SB - 16) * gw + xx;
+                for (int k = 0; k < 32; k++) col[k] = s[(size_t)k * gw];
+                ffv2o_inv_lap_filter32(col);
+                for (int k = 0; k < 32; k++) s[(size_t)k * gw] = col[k];
+            }
+        for (int yy = 0; yy < gh; yy++)
+            for (int i = 1; i < nsx; i++)
+                ffv2o_inv_lap_filter32(pl + (size_t)yy * gw + i * SB - 16);
+        for (int yy = 0; yy < height; yy++) {
+            uint8_t *row = data[p] + (ptrdiff_t)yy * linesize[p];
+            const int32_t *srow = pl + (size_t)yy * gw;
+            for (int xx = 0; xx < width; xx++) {
+                int32_t v = (srow[xx] + 2048) >> (12 - depth);
+                if (depth == 8) {
+                    row[xx] = (uint8_t)v;
+                } else {
+                    uint16_t w = (uint16_t)v;
+                    memcpy(row + 2 * xx, &w, 2);
+                }
+            }
+        }
+    }
+    free(pl);
     return 0;
 }
 

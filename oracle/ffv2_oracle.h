@@ -67,6 +67,15 @@ int ffv2o_tstage(const uint8_t *const data[4], const ptrdiff_t linesize[4],
                  int width, int height, int pix_fmt,
                  int32_t *coef, int64_t *energy);
 
+/* Decoder-side inverse of the T-stage (ffv2.c:81-98, :4962-4972, :216-239 with the
+ * seam order of ffv2dec.c, :40-52): coding-order coefficients -> picture planes.
+ * Not an exact inverse (the post-filter divides with truncation); used for round-trip
+ * self checks. */
+void ffv2o_idct64(int32_t *x, int xstride, const int32_t y[64]);
+void ffv2o_inv_lap_filter32(int32_t x[32]);
+int ffv2o_inverse_tstage(const int32_t *coef, int width, int height, int pix_fmt,
+                         uint8_t *const data[4], const ptrdiff_t linesize[4]);
+
 /* Whole frame -> one packet (ffv2enc.c:453-493).
  *   W : optional phantom coefficient per block-plane, NULL = 0. */
 int ffv2o_encode_frame(const uint8_t *const data[4], const ptrdiff_t linesize[4],

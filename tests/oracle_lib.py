@@ -71,6 +71,27 @@ class Oracle:
             self.lib.ffv2o_fdct64(y[i].ctypes.data_as(C.c_void_p), x[i].ctypes.data_as(C.c_void_p), C.c_int(1))
         return y
 
+    def idct64(self, y):
+        y = np.ascontiguousarray(y, np.int32)
+        x = np.zeros_like(y)
+        for i in range(y.shape[0]):
+            self.lib.ffv2o_idct64(x[i].ctypes.data_as(C.c_void_p), C.c_int(1), y[i].ctypes.data_as(C.c_void_p))
+        return x
+
+    def inverse_tstage(self, coef, pix_fmt, P, H, W, depth):
+        coef = np.ascontiguousarray(coef, np.int32)
+        out = np.zeros((P, H, W), np.uint8 if depth == 8 else np.uint16)
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(P):
+            data[p] = out[p].ctypes.data
+            ls[p] = out[p].strides[0]
+        r = self.lib.ffv2o_inverse_tstage(coef.ctypes.data_as(C.c_void_p), C.c_int(W), C.c_int(H),
+                                          C.c_int(PIX[pix_fmt]), data, ls)
+        if r < 0:
+            raise RuntimeError("oracle error %d" % r)
+        return out
+
     def lap32(self, x):
         x = np.ascontiguousarray(x, np.int32)
         y = np.zeros_like(x)

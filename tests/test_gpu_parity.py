@@ -186,6 +186,35 @@ def test_gain_table_overflow_is_an_error():
     enc.close()
 
 
+# ---- decoder-side inverse of the T-stage (round-trip self check) ----
+@pytest.mark.parametrize("fmt,P,H,W,depth", CASES)
+def test_inverse_tstage_matches_oracle_on_arbitrary_coefficients(oracle, fmt, P, H, W, depth):
+    import torch
+    enc = _enc(W, H, fmt)
+    rng = np.random.default_rng(H * 1000 + W)
+    nb = enc.info.block_planes
+    coef = (rng.standard_normal((1, nb, 4096)) * rng.choice([30, 3000, 200000], (1, nb, 1))).astype(np.int32)
+    coef[0, 0, :] = 0
+    coef[0, -1, :16] = 2 ** 20
+    got = enc.unpack_frames(enc.inverse_tstage(torch.from_numpy(coef).cuda()).cpu().numpy())[0]
+    want = oracle.inverse_tstage(coef[0], fmt, P, H, W, depth)
+    assert np.array_equal(got, want)
+    enc.close()
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", CASES + [("yuv444p10le", 3, 2160, 3840, 10), ("yuv444p12le", 3, 4320, 7680, 12)])
+def test_round_trip_is_exact(fmt, P, H, W, depth):
+    """Size-independent property, no oracle: inverse(tstage(x)) == x, bit for bit, for every sample
+    (the lifting DCT is exactly invertible and so is the lapping pair on level-shifted picture data)."""
+    enc = _enc(W, H, fmt)
+    for kind in ("S1", "S2"):
+        fr = synth.make(kind, 5, P, H, W, depth)
+        coef, _ = enc.tstage(enc.upload(fr[None]), want_energy=False)
+        rec = enc.unpack_frames(enc.inverse_tstage(coef).cpu().numpy())[0]
+        assert np.array_equal(rec, fr), "%s: %d samples differ" % (kind, int((rec != fr).sum()))
+    enc.close()
+
+
 def test_full_size_properties_8k12():
     """BASELINE config 5 size: properties that need no oracle run.
     * determinism, * frame independence inside a batch (ffv2enc.c:461-469: no

@@ -55,11 +55,11 @@ ROOT = os.path.dirname(HERE)
 # --------------------------------------------------------------------------
 # 1. excerpt + preprocess
 # --------------------------------------------------------------------------
-def expanded_statements(ref):
+def expanded_statements(ref, func="od_bin_fdct64"):
     src = open(os.path.join(ref, "libavcodec/ffv2.c")).read().split("\n")
     start = next(i for i, l in enumerate(src) if l.startswith("#define OD_RSHIFT1"))
     end = next(i for i, l in enumerate(src) if l.startswith("static void od_bin_fdct4("))
-    f0 = next(i for i, l in enumerate(src) if l.startswith("static void od_bin_fdct64("))
+    f0 = next(i for i, l in enumerate(src) if l.startswith("static void %s(" % func))
     f1 = next(i for i in range(f0, len(src)) if src[i] == "}")
     text = ["#define dctcoef int", "#define OD_DCT_OVERFLOW_CHECK(a,b,c,d)"]
     text += src[start:end] + src[f0:f1 + 1]
@@ -177,9 +177,9 @@ class Lowerer:
         return None
 
     def statement(self, text):
-        m = re.match(r"y\[(\d+)\] = (\w+)$", text)
+        m = re.match(r"(?:y\[(\d+)\]|x\[(\d+)\*xstride\]) = (\w+)$", text)
         if m:
-            self.outputs[int(m.group(1))] = self.lookup(m.group(2))
+            self.outputs[int(m.group(1) or m.group(2))] = self.lookup(m.group(3))
             return
         node = ast.parse(text).body[0]
         if isinstance(node, ast.AugAssign):
@@ -231,10 +231,10 @@ class Lowerer:
             elif tok[0] == "decl":
                 r = self.declare(tok[1])
                 if tok[2] is not None:
-                    m = re.match(r"x\[(\d+)\*xstride\]$", tok[2])
+                    m = re.match(r"(?:x\[(\d+)\*xstride\]|y\[(\d+)\])$", tok[2])
                     if not m:
                         raise ValueError("unhandled initialiser: " + tok[2])
-                    self.inputs[int(m.group(1))] = r
+                    self.inputs[int(m.group(1) or m.group(2))] = r
             else:
                 self.statement(tok[1])
         assert sorted(self.inputs) == list(range(64))
@@ -288,14 +288,15 @@ def numeric_golden(body, xs):
             uid[0] += 1
             scopes[-1][tok[1]] = u
             if tok[2] is not None:
-                k = int(re.match(r"x\[(\d+)\*xstride\]$", tok[2]).group(1))
+                mm = re.match(r"(?:x\[(\d+)\*xstride\]|y\[(\d+)\])$", tok[2])
+                k = int(mm.group(1) or mm.group(2))
                 env[u] = xs[:, k].copy()
             else:
                 env[u] = np.zeros(xs.shape[0], dtype=np.int64)
         else:
-            m = re.match(r"y\[(\d+)\] = (\w+)$", tok[1])
+            m = re.match(r"(?:y\[(\d+)\]|x\[(\d+)\*xstride\]) = (\w+)$", tok[1])
             if m:
-                ys[:, int(m.group(1))] = env[resolve(m.group(2))]
+                ys[:, int(m.group(1) or m.group(2))] = env[resolve(m.group(3))]
                 continue
             # (a < 0) must be 0/1 ints, >> is arithmetic on int64: numpy does both.
             py = rewrite(tok[1])
@@ -366,6 +367,21 @@ def main():
     np.savez_compressed(os.path.join(gold, "fdct64_vectors.npz"),
                         x=xs.astype(np.int32), y=ys.astype(np.int32))
     print("golden vectors:", xs.shape)
+
+    # inverse transform (decoder side): od_bin_idct64, ffv2.c:4814-4948
+    ibody = expanded_statements(args.ref, "od_bin_idct64")
+    ilow = Lowerer()
+    ilow.run(ibody)
+    iir = compact(ilow)
+    print("idct ops:", len(iir["ops"]), "regs:", iir["n_regs"])
+    json.dump(iir, open(os.path.join(gen, "idct64_ir.json"), "w"))
+    # golden: coefficient vectors = forward outputs of the golden inputs (plus some raw noise)
+    cs = np.concatenate([ys[:224], rng.integers(-3000, 3001, (64, 64))]).astype(np.int64)
+    rs = numeric_golden(ibody, cs)
+    assert np.abs(rs).max() < 2 ** 31
+    np.savez_compressed(os.path.join(gold, "idct64_vectors.npz"), y=cs.astype(np.int32), x=rs.astype(np.int32))
+    print("inverse golden vectors:", cs.shape, "max |idct(fdct(x)) - x| on the first 224:",
+          int(np.abs(rs[:224] - xs[:224]).max()))
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -645,6 +646,7 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
         }
         return FFV2AMD_OK;
     }
+    const auto t_begin = std::chrono::steady_clock::now();
     // qp > 0: T-stage with coefficients kept, PVQ search, then the host range coder
     if (!e->d_coef_ws) {
         HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
@@ -664,6 +666,8 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
                           hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_status, e->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const bool trace = getenv("FFV2AMD_TRACE") != nullptr;
+    const auto t_dev = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int f = 0; f < nframes; f++) {
         if (h_status[f] < 0) { h_sizes[f] = 0; continue; }
@@ -677,6 +681,12 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
         });
     }
     for (auto &t : pool) t.join();
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "ffv2amd: qp=%d batch of %d: device (T-stage + PVQ + copies) %.3f ms, host range coder %.3f ms\n",
+                qp, nframes, std::chrono::duration<double, std::milli>(t_dev - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_dev).count());
+    }
     return FFV2AMD_OK;
 }
 

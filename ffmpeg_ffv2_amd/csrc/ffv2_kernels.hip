@@ -8,7 +8,8 @@
 //   band energies/gain ffv2enc.c:163-166,174
 // E-stage at qp == 0 (ffv2enc.c:105-123,148-150,174,197 + daala_entropy.c:227-270,
 // 698-721): every data-dependent symbol is a raw bit, so the packet tail is an
-// exclusive prefix sum over code lengths followed by a scatter of the codes.
+// exclusive prefix sum over code lengths followed by a scatter of the codes (one launch:
+// each workgroup recomputes its prefix from the 24 KB of bit counts, assembles in LDS).
 //
 // Work decomposition: ONE wavefront (64 lanes) owns one 64x64 block-plane.  It
 // stages the 96x96 halo tile (16 samples each side, what the two lapping passes
@@ -17,7 +18,8 @@
 // raster buffer for the scan-order gather.  Eight such workgroups fit a CU
 // (2 waves per SIMD).  HBM sees each source sample ~once (halo re-reads hit L2:
 // block ids are dealt so that an XCD owns a contiguous run of superblocks) and
-// each coefficient exactly once, written in coding order, 256 B per wave store.
+// each coefficient exactly once, written in coding order, 1 KiB per wave store (16 B per lane),
+// issued last so that no load has to wait behind them (vmcnt is in-order).
 // Integer lifting only; no MFMA.
 //
 // Exactness notes:

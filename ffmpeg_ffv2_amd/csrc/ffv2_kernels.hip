@@ -44,7 +44,15 @@ __device__ __forceinline__ int ffv2_rsh1(int a)
     return t >> 1;
 }
 #define FFV2_RSH1(a)            ffv2_rsh1(a)
-#define FFV2_MULRS(a, K, R, S)  ((__mul24((a), (K)) + (R)) >> (S))
+// (a*K + R) >> S with R = 2^(S-1).  Row pass: v_mad_i32_i24 + shift, bit-identical to the
+// reference's wrapping int32 even where that overflows (|a| < 2^23).  Column pass: inputs
+// are bounded by 2.31e4 so a*K + R cannot overflow int32 (max over the network of
+// L1(operand)*K is 59 914), and for K/2^S < 1/2 the same value is the high dword of
+// a*(K << (32-S)) + 2^31: one v_mad_i64_i32 instead of multiply + shift.
+#define FFV2_MULRS_WRAP(a, K, R, S)  ((__mul24((a), (K)) + (R)) >> (S))
+#define FFV2_MULRS_NOOVF(a, K, R, S) (((K) < (1 << ((S) - 1))) \
+    ? (int)(((long long)(a) * (int)((long long)(K) << (32 - (S))) + 0x80000000LL) >> 32) \
+    : FFV2_MULRS_WRAP(a, K, R, S))
 
 namespace {
 
@@ -101,12 +109,16 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)l
 // at encoder creation; the float estimate below only seeds the search.
 __device__ __forceinline__ uint32_t coded_gain(long long e, const int64_t *thr, int n, bool &out_of_table)
 {
-    float g = sqrtf((float)e);
-    int v = (int)exp2f(log2f(g + 1e-30f) * 0.6666667f);
-    v = v < 0 ? 0 : (v > n ? n : v);
-    while (v > 0 && thr[v - 1] > e) v--;
-    while (v < n && thr[v] <= e) v++;
-    if (v >= n) out_of_table = true;
+    // gain = #{k : thr[k] <= e}.  The float estimate is within +-1 of it; five independent
+    // probes around the estimate (a fixed number of loads: the compiler can then count
+    // vmcnt exactly) bracket it, anything else is reported instead of guessed.
+    const float g = sqrtf((float)e);
+    int v0 = (int)exp2f(log2f(g + 1e-30f) * 0.6666667f);
+    v0 = v0 < 2 ? 2 : (v0 > n - 3 ? n - 3 : v0);
+    const long long t0 = thr[v0 - 2], t1 = thr[v0 - 1], t2 = thr[v0], t3 = thr[v0 + 1], t4 = thr[v0 + 2];
+    const int v = (v0 - 2) + (e >= t0) + (e >= t1) + (e >= t2) + (e >= t3);
+    // consistent iff everything below the window is <= e and the probe above is > e
+    if ((v0 > 2 && e < t0) || e >= t4) out_of_table = true;
     return (uint32_t)v;
 }
 
@@ -270,6 +282,30 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
                 const int nvalid = ok ? g.width - x0 : 0;    // samples of this vector inside the picture
                 const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
                 int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + cv * EPV);
+                if (g.width % EPV == 0) {
+                    // the picture ends on a vector boundary: a vector is inside or outside as a whole
+                    const uint32_t m = ok ? 0xffffffffu : 0u;
+                    if (BPS == 1) {
+                        uint32_t o[8];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            o[2 * k]     = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u) << sh) & m;
+                            o[2 * k + 1] = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u) << sh) & m;
+                        }
+                        dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                        dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+                    } else {
+                        uint32_t o[4];
+                        const uint32_t himask = ~(((1u << g.depth) - 1u) * 0x00010001u);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            bad |= w[k] & himask;                 // w is 0 where the vector is outside
+                            o[k] = pk_sub2048(w[k] << sh) & m;
+                        }
+                        dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                    }
+                    continue;
+                }
                 if (BPS == 1) {
                     uint32_t o[8];
 #pragma unroll
@@ -368,7 +404,9 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         asm("" : "+v"(x[k]));
     }
     __syncthreads();                                         // tile is dead: LDS becomes int32 [64][65]
+#define FFV2_MULRS FFV2_MULRS_NOOVF
     FDCT64_NET(x);
+#undef FFV2_MULRS
 #pragma unroll
     for (int v = 0; v < 64; v++) xb[lane * XPITCH + v] = x[OUTR[v]];      // tmp[64*col + v], ffv2.c:4957
     __syncthreads();
@@ -377,7 +415,9 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 #pragma unroll
     for (int k = 0; k < 64; k++) x[k] = xb[k * XPITCH + lane];            // tmp + v, stride 64, ffv2.c:4959
     __syncthreads();
+#define FFV2_MULRS FFV2_MULRS_WRAP
     FDCT64_NET(x);
+#undef FFV2_MULRS
 #pragma unroll
     for (int u = 0; u < 64; u++) xb[lane * RPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
     __syncthreads();

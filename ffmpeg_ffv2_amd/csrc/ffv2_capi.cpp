@@ -301,7 +301,15 @@ struct ffv2amd_encoder {
     // options
     int32_t *coef_sink = nullptr;
     bool profiling = false;
-    struct EvTriple { hipEvent_t a, b, c; };
+    struct EvTriple { hipEvent_t a, b, c, d; };     // T start, T end, E end, E start
+    // pipelined mode: the E-stage of call n runs on e_stream while the caller's stream
+    // already carries the T-stage of call n+1; two sets of T->E hand-off buffers
+    bool pipelined = false;
+    hipStream_t e_stream = nullptr;
+    hipEvent_t evT[2] = { nullptr, nullptr }, evE[2] = { nullptr, nullptr };
+    bool evE_valid[2] = { false, false };
+    uint32_t *d_codes2 = nullptr, *d_bitoff2 = nullptr;
+    unsigned seq = 0;
     std::vector<EvTriple> ev_pool;       // reused
     size_t ev_used = 0;
     double prof_t = 0, prof_e = 0;
@@ -344,7 +352,10 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     if (e->h_frame) (void)hipHostFree(e->h_frame);
     if (e->h_pkt) (void)hipHostFree(e->h_pkt);
     if (e->h_meta) (void)hipHostFree(e->h_meta);
-    for (auto &t : e->ev_pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); }
+    for (auto &t : e->ev_pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
+    if (e->e_stream) { (void)hipStreamSynchronize(e->e_stream); (void)hipStreamDestroy(e->e_stream); }
+    for (int i = 0; i < 2; i++) { if (e->evT[i]) (void)hipEventDestroy(e->evT[i]); if (e->evE[i]) (void)hipEventDestroy(e->evE[i]); }
+    (void)hipFree(e->d_codes2); (void)hipFree(e->d_bitoff2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -470,12 +481,18 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
     int32_t *status = d_status ? d_status : e->d_status;
+    const bool pipe = e->pipelined;
+    const int pb = pipe ? (int)(e->seq++ & 1u) : 0;
+    uint32_t *codes = pb ? e->d_codes2 : e->d_codes, *bitcnt = pb ? e->d_bitoff2 : e->d_bitoff;
+    hipStream_t se = pipe ? e->e_stream : s;       // stream of the E-stage
+    if (pipe && e->evE_valid[pb])                  // the E-stage two calls ago read this hand-off buffer
+        HIPCHK(hipStreamWaitEvent(s, e->evE[pb], 0));
     HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, s));
-    HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, s));
+    if (!pipe) HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, s));
 
     FFV2TStageArgs a{};
     a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
-    a.coef = nullptr; a.energy = nullptr; a.codes = e->d_codes; a.bitcnt = e->d_bitoff; a.W = d_W;
+    a.coef = nullptr; a.energy = nullptr; a.codes = codes; a.bitcnt = bitcnt; a.W = d_W;
     a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
     a.status = status;
     a.coef = e->coef_sink;
@@ -489,6 +506,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
             } else {
                 ffv2amd_encoder::EvTriple t{};
                 HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.c));
+                HIPCHK(hipEventCreate(&t.d));
                 e->ev_pool.push_back(t);
             }
         }
@@ -497,17 +515,55 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     }
     HIPCHK(ffv2_launch_tstage(a, s));
     if (ev) HIPCHK(hipEventRecord(ev->b, s));
+    if (pipe) {
+        HIPCHK(hipEventRecord(e->evT[pb], s));
+        HIPCHK(hipStreamWaitEvent(se, e->evT[pb], 0));
+        HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, se));
+    }
+    if (ev) HIPCHK(hipEventRecord(ev->d, se));
 
     FFV2EStageArgs b{};
-    b.g = e->geom; b.nframes = nframes; b.codes = e->d_codes; b.bitoff = e->d_bitoff;
+    b.g = e->geom; b.nframes = nframes; b.codes = codes; b.bitoff = bitcnt;
     b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
     b.sizes = d_sizes; b.status = status;
     b.prefix = e->d_prefix; b.prefix_len = e->prefix_len; b.slack_bits = e->slack;
     // raw header: pix_fmt & 15 (daala_entropy.c:406), then Exp-Golomb(qp = 0) = "1"
     b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
     b.header_nbits = 5;
-    HIPCHK(ffv2_launch_estage_qp0(b, s));
-    if (ev) HIPCHK(hipEventRecord(ev->c, s));
+    HIPCHK(ffv2_launch_estage_qp0(b, se));
+    if (ev) HIPCHK(hipEventRecord(ev->c, se));
+    if (pipe) {
+        HIPCHK(hipEventRecord(e->evE[pb], se));
+        e->evE_valid[pb] = true;
+    }
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encoder_set_pipelined(ffv2amd_encoder *e, int on)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    HIPCHK(hipSetDevice(e->device));
+    if (on && !e->e_stream) {
+        const size_t nb = (size_t)e->info.block_planes, B = (size_t)e->info.max_batch;
+        HIPCHK(hipStreamCreateWithFlags(&e->e_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&e->evT[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->evE[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipMalloc(&e->d_codes2, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B));
+        HIPCHK(hipMalloc(&e->d_bitoff2, sizeof(uint32_t) * nb * B));
+    }
+    if (!on && e->pipelined) HIPCHK(hipStreamSynchronize(e->e_stream));
+    e->pipelined = on != 0;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encoder_flush(ffv2amd_encoder *e, void *stream)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    HIPCHK(hipSetDevice(e->device));
+    for (int i = 0; i < 2; i++)
+        if (e->evE_valid[i]) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evE[i], 0));
     return FFV2AMD_OK;
 }
 
@@ -534,7 +590,7 @@ int ffv2amd_profile_read(ffv2amd_encoder *e, double *tstage_ms, double *estage_m
         float ms = 0;
         HIPCHK(hipEventSynchronize(e->ev_pool[i].c));
         HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b)); t += ms;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].b, e->ev_pool[i].c)); x += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].d, e->ev_pool[i].c)); x += ms;
         n++;
     }
     e->ev_used = 0;
@@ -580,6 +636,7 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     int r = ffv2amd_encode_batch_device(e, 1, e->d_frame, qp, dW, e->d_pkt, in.packet_cap,
                                         e->d_meta, (int32_t *)(e->d_meta + 1), s);
     if (r < 0) return r;
+    HIPCHK(ffv2amd_encoder_flush(e, s) < 0 ? hipErrorUnknown : hipSuccess);
     HIPCHK(hipMemcpyAsync(e->h_meta, e->d_meta, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(e->h_pkt, e->d_pkt, in.packet_cap, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -634,6 +691,7 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
         int r = ffv2amd_encode_batch_device(e, nframes, d_frames, 0, d_W, e->d_pk_ws, in.packet_cap,
                                             e->d_sizes_ws, e->d_status, s);
         if (r < 0) return r;
+        HIPCHK(ffv2amd_encoder_flush(e, s) < 0 ? hipErrorUnknown : hipSuccess);
         std::vector<uint8_t> tmp(in.packet_cap * (size_t)nframes);
         HIPCHK(hipMemcpyAsync(h_sizes, e->d_sizes_ws, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(h_status, e->d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));

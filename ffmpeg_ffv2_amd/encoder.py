@@ -187,6 +187,16 @@ class FFV2Encoder:
         _lib.check(self._lib.ffv2amd_encoder_set_coef_sink(
             self._h, d_coef.data_ptr() if d_coef is not None else None), "set_coef_sink")
 
+    def set_pipelined(self, on=True):
+        """E-stage of call n overlaps the T-stage of call n+1 (alternate two output sets)."""
+        _lib.check(self._lib.ffv2amd_encoder_set_pipelined(self._h, 1 if on else 0), "set_pipelined")
+
+    def flush(self, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+        _lib.check(self._lib.ffv2amd_encoder_flush(self._h, C.c_void_p(stream)), "flush")
+
     def profile(self, on=True):
         _lib.check(self._lib.ffv2amd_profile_enable(self._h, 1 if on else 0), "profile_enable")
 

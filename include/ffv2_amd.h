@@ -134,6 +134,14 @@ int  ffv2amd_pvq_search_device(ffv2amd_encoder *enc, const float *d_X, int strid
  * to turn it off again.  Same kernel launch, no extra pass. */
 int  ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *enc, int32_t *d_coef);
 
+/* Pipelined mode ("one batch per stream"): the E-stage of *_batch_device call n is issued on
+ * an internal stream behind an event, so the caller's stream can already run the T-stage of
+ * call n+1.  Consecutive calls must then use different d_packets/d_sizes/d_status buffers
+ * (two sets suffice), and ffv2amd_encoder_flush(enc, stream) makes `stream` wait for every
+ * E-stage issued so far (a device-wide synchronise does too). Off by default. */
+int  ffv2amd_encoder_set_pipelined(ffv2amd_encoder *enc, int on);
+int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around the
  * T-stage kernel and around the E-stage kernels of every *_batch_device call.
  * profile_read waits for the recorded events, returns the summed durations (ms)

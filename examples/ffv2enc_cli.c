@@ -1,0 +1,77 @@
+/*
+ * ffv2enc_cli.c -- raw planar 4:4:4 frames in, concatenated FFV2 packets out, through the
+ * AVCodec-shaped host shim (include/ffv2_amd_codec.h).  The equivalent of
+ *   ffmpeg -f rawvideo -s WxH -pix_fmt FMT -i in.yuv -c:v ffv2 -strict -2 -f rawvideo out.ffv2
+ * on a machine that has an MI355X but no FFmpeg: the rawvideo
+ * muxer writes packets back to back, which is what the reference's known-answer md5s are taken over.
+ *
+ *   ffv2enc_cli WIDTH HEIGHT PIX_FMT IN.yuv OUT.ffv2 [QP] [HIP_DEVICE]
+ *   PIX_FMT: gray | yuv444p | yuv444p10le | yuv444p12le | gbrp | gbrp10le | gbrp12le
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ffv2_amd.h"
+#include "ffv2_amd_codec.h"
+
+static int parse_fmt(const char *s, int *planes, int *bps)
+{
+    static const struct { const char *n; int id, planes, bps; } tab[] = {
+        { "gray", FFV2AMD_PIX_GRAY8, 1, 1 },           { "yuv444p", FFV2AMD_PIX_YUV444P, 3, 1 },
+        { "gbrp", FFV2AMD_PIX_GBRP, 3, 1 },            { "yuv444p10le", FFV2AMD_PIX_YUV444P10LE, 3, 2 },
+        { "gbrp10le", FFV2AMD_PIX_GBRP10LE, 3, 2 },    { "yuv444p12le", FFV2AMD_PIX_YUV444P12LE, 3, 2 },
+        { "gbrp12le", FFV2AMD_PIX_GBRP12LE, 3, 2 },
+    };
+    for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
+        if (!strcmp(s, tab[i].n)) { *planes = tab[i].planes; *bps = tab[i].bps; return tab[i].id; }
+    return -1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) {
+        fprintf(stderr, "usage: %s WIDTH HEIGHT PIX_FMT IN.yuv OUT.ffv2 [QP] [HIP_DEVICE]\n", argv[0]);
+        return 2;
+    }
+    int planes = 0, bps = 0;
+    FFV2AMDCodecContext ctx = { 0 };
+    ctx.width = atoi(argv[1]);
+    ctx.height = atoi(argv[2]);
+    ctx.pix_fmt = parse_fmt(argv[3], &planes, &bps);
+    ctx.global_quality = argc > 6 ? atoi(argv[6]) : 0;
+    ctx.hip_device = argc > 7 ? atoi(argv[7]) : 0;
+    if (ctx.pix_fmt < 0) { fprintf(stderr, "unsupported pix_fmt %s (the encoder takes 4:4:4 planar only)\n", argv[3]); return 2; }
+    FILE *in = strcmp(argv[4], "-") ? fopen(argv[4], "rb") : stdin;
+    FILE *out = strcmp(argv[5], "-") ? fopen(argv[5], "wb") : stdout;
+    if (!in || !out) { perror("open"); return 1; }
+    int ret = ffv2amd_codec_init(&ctx);
+    if (ret < 0) { fprintf(stderr, "init failed: %d\n", ret); return 1; }
+
+    const size_t plane_bytes = (size_t)ctx.width * ctx.height * bps;
+    uint8_t *buf = malloc(plane_bytes * planes);
+    if (!buf) return 1;
+    long nframes = 0;
+    size_t nbytes = 0;
+    while (fread(buf, 1, plane_bytes * planes, in) == plane_bytes * planes) {
+        FFV2AMDFrame fr = { 0 };
+        FFV2AMDPacket pkt = { 0 };
+        int got = 0;
+        for (int p = 0; p < planes; p++) {
+            fr.data[p] = buf + p * plane_bytes;
+            fr.linesize[p] = (ptrdiff_t)ctx.width * bps;
+        }
+        fr.pts = nframes;
+        ret = ffv2amd_codec_encode2(&ctx, &pkt, &fr, &got);
+        if (ret < 0 || !got) { fprintf(stderr, "encode2 failed on frame %ld: %d\n", nframes, ret); break; }
+        fwrite(pkt.data, 1, (size_t)pkt.size, out);
+        nbytes += (size_t)pkt.size;
+        ffv2amd_packet_unref(&pkt);
+        nframes++;
+    }
+    ffv2amd_codec_close(&ctx);
+    free(buf);
+    if (out != stdout) fclose(out);
+    fprintf(stderr, "%ld frames, %zu bytes\n", nframes, nbytes);
+    return ret < 0 ? 1 : 0;
+}

@@ -654,14 +654,18 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
 
     // (2) codes -> LDS
     if (have) {
-        const uint32_t *rec = a.codes + ((size_t)f * n + i) * FFV2_CODES_PER_BP;
+        // the whole 64-byte record in one go: four independent 16-byte loads, one latency
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.codes + ((size_t)f * n + i) * FFV2_CODES_PER_BP);
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+        const uint32_t rec[14] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
+                                   r2.x, r2.y, r2.z, r2.w, r3.x, r3.y };
         LdsBitSink s;
         s.init(bits, a.header_nbits + before + wbase + (incl - mine) + tx - lbase);
         const int c0 = (int)rec[0];
         const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
         put_golomb(s, mag);                                   // ffv2enc.c:148-150
         if (c0) s.put(c0 < 0 ? 1u : 0u, 1);
-#pragma unroll 1
+#pragma unroll
         for (int b = 0; b < FFV2_NUM_BANDS; b++)
             put_golomb(s, rec[1 + b]);                        // ffv2enc.c:174
         s.flush();

@@ -151,6 +151,12 @@ def test_batch_device_api_with_phantom_w(oracle):
     pk = enc.collect(*enc.encode_batch_device(enc.upload(fr[:2])))
     for n in range(2):
         assert pk[n] == oracle.encode(fr[n], fmt)
+    # the synchronous to-host variant at qp = 0 is the same device path plus the copy back
+    assert enc.encode_batch_to_host(enc.upload(fr[:3]), qp=0) == [oracle.encode(fr[n], fmt) for n in range(3)]
+    i = enc.info
+    assert (i.num_sb_x, i.num_sb_y, i.planes, i.depth, i.block_planes) == (5, 4, 3, 8, 60)
+    assert i.tstage_bytes_per_frame == 3 * 320 * 240 + 3 * 320 * 256 * 4      # 1 213 440
+    assert i.row_pitch % 16 == 0 and i.frame_stride == i.plane_stride * 3
     enc.close()
 
 

@@ -211,6 +211,17 @@ def test_random_geometries(oracle):
         enc.close()
 
 
+@pytest.mark.parametrize("fmt,P,H,W,depth", [("gray", 1, 1, 1, 8), ("yuv444p", 3, 64, 8192, 8), ("gray", 1, 8192, 64, 8),
+                                             ("yuv444p10le", 3, 65, 4097, 10), ("gbrp12le", 3, 2, 3000, 12)])
+def test_extreme_geometries(oracle, fmt, P, H, W, depth):
+    enc = _enc(W, H, fmt)
+    fr = synth.noise(9, P, H, W, depth)
+    assert enc.encode2(fr) == oracle.encode(fr, fmt)
+    coef, _ = enc.tstage(enc.upload(fr[None]), want_energy=False)
+    assert np.array_equal(enc.unpack_frames(enc.inverse_tstage(coef).cpu().numpy())[0], fr)
+    enc.close()
+
+
 def test_gain_table_overflow_is_an_error():
     from ffmpeg_ffv2_amd import FFV2Error
     enc = _enc(64, 64, "gray")

@@ -132,12 +132,13 @@ __device__ __forceinline__ int golomb_len(uint32_t val)      // ffv2enc.c:105-12
 // ---------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// two int16 fields of a dword minus 2048 each (v_pk_sub_i16)
-__device__ __forceinline__ uint32_t pk_sub2048(uint32_t w)
+// level shift of two packed samples in one instruction: (s << sh) - 2048 per 16-bit field
+// as s * 2^sh + 0xF800 (mod 2^16), mul = (1 << sh) * 0x00010001
+__device__ __forceinline__ uint32_t pk_level_shift(uint32_t w, uint32_t mul)
 {
-    s16x2 v = __builtin_bit_cast(s16x2, w);
-    v -= (s16x2)(2048);
-    return __builtin_bit_cast(uint32_t, v);
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mul), "v"(0xF800F800u));
+    return r;
 }
 
 // inclusive prefix sum over the 64 lanes, DPP only (no LDS crossbar)
@@ -183,18 +184,18 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     const FFV2Geom &g = a.g;
     const int lane = threadIdx.x;
 
-    // XCD-aware block id: ids b and b+8 share an XCD (round-robin dispatch), so
-    // give each XCD one contiguous run of block-planes -> neighbouring tiles,
-    // which share their 32-sample halos, meet in the same L2.
-    const long long total = (long long)a.nframes * g.nblk;
-    const long long chunk = (total + 7) >> 3;
-    const long long id = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= chunk || id >= total) return;
-    const int f   = (int)(id / g.nblk);
-    const int bp  = (int)(id - (long long)f * g.nblk);
-    const int sb  = bp / g.planes;
+    // XCD-aware block id: workgroups b and b+8 share an XCD (round-robin dispatch; gridDim.x
+    // is a multiple of 8 and blockIdx.y = frame), so give each XCD one contiguous run of the
+    // frame's block-planes -> neighbouring tiles, which share their 32-sample halos, meet in
+    // the same L2.  All of it 32-bit and scalar: no 64-bit divide on the way in.
+    const uint32_t chunk = gridDim.x >> 3;
+    const uint32_t ubp = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (ubp >= (uint32_t)g.nblk) return;
+    const int f   = (int)blockIdx.y;
+    const int bp  = (int)ubp;
+    const int sb  = (int)(ubp / (uint32_t)g.planes);
     const int p   = bp - sb * g.planes;
-    const int sby = sb / g.nsx;
+    const int sby = (int)((uint32_t)sb / (uint32_t)g.nsx);
     const int sbx = sb - sby * g.nsx;
 
     const uint8_t *plane = a.frames + (size_t)f * g.frame_stride + (size_t)p * g.plane_stride;
@@ -221,32 +222,40 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         const bool inside = (x_org >= 0) & (x_org + TILE <= g.width) & (y_org >= 0) & (y_org + TILE <= g.height);
         uint4 v[PER_LANE];
         uint32_t bad = 0;
+        const uint32_t lsmul = (1u << sh) * 0x00010001u;
         if (inside) {                              // wave-uniform: no per-sample masking needed
-            int r = lane / VPR, cv = lane - (lane / VPR) * VPR;
-            uint32_t off = (uint32_t)(y_org + r) * (uint32_t)g.row_pitch + (uint32_t)(x_org + cv * EPV) * BPS;
-            const uint32_t step = RSTEP * (uint32_t)g.row_pitch + CSTEP * 16;
-            const uint32_t wrap = (uint32_t)g.row_pitch - VPR * 16;
-            int cvi = cv;
+            // vector index of iteration `it` is it*64 + lane.  64 = RSTEP*VPR + 4 and 3*4 is a
+            // multiple of VPR (6 | 12), so (row, column) repeat every three iterations, shifted
+            // down by 192/VPR rows: three address phases, everything else is a constant step.
+            static_assert((3 * CSTEP) % VPR == 0, "three-phase addressing");
+            constexpr int RSTEP3 = 3 * 64 / VPR;
+            uint32_t goff[3];
+            int doff3[3];
+            {
+                int r = lane / VPR, cv = lane - (lane / VPR) * VPR;
 #pragma unroll
-            for (int it = 0; it < PER_LANE; it++) {
-                v[it] = *reinterpret_cast<const uint4 *>(plane + off);
-                off += step;
-                cvi += CSTEP;
-                if (cvi >= VPR) { cvi -= VPR; off += wrap; }
+                for (int ph = 0; ph < 3; ph++) {
+                    goff[ph]  = (uint32_t)(y_org + r) * (uint32_t)g.row_pitch + (uint32_t)(x_org + cv * EPV) * BPS;
+                    doff3[ph] = r * TPITCH + cv * EPV;          // int16 units
+                    r += RSTEP; cv += CSTEP;
+                    if (cv >= VPR) { cv -= VPR; r++; }
+                }
             }
-            int doff = r * TPITCH + cv * EPV;      // int16 units
-            cvi = cv;
-            const uint32_t himask = ~(((1u << g.depth) - 1u) * 0x00010001u);
+            const uint32_t gstep = RSTEP3 * (uint32_t)g.row_pitch;
+#pragma unroll
+            for (int it = 0; it < PER_LANE; it++)
+                v[it] = *reinterpret_cast<const uint4 *>(plane + (goff[it % 3] + (uint32_t)(it / 3) * gstep));
+            uint32_t seen = 0;                     // OR of every sample word: one depth test at the end
 #pragma unroll
             for (int it = 0; it < PER_LANE; it++) {
                 const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
-                int4 *dst = reinterpret_cast<int4 *>(tile + doff);
+                int4 *dst = reinterpret_cast<int4 *>(tile + doff3[it % 3] + (it / 3) * RSTEP3 * TPITCH);
                 if (BPS == 1) {
                     uint32_t o[8];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        o[2 * k]     = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u) << sh);
-                        o[2 * k + 1] = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u) << sh);
+                        o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul);
+                        o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul);
                     }
                     dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                     dst[1] = make_int4(o[4], o[5], o[6], o[7]);
@@ -254,15 +263,13 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
                     uint32_t o[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        bad |= w[k] & himask;
-                        o[k] = pk_sub2048(w[k] << sh);
+                        seen |= w[k];
+                        o[k] = pk_level_shift(w[k], lsmul);
                     }
                     dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                 }
-                doff += RSTEP * TPITCH + CSTEP * EPV;
-                cvi += CSTEP;
-                if (cvi >= VPR) { cvi -= VPR; doff += TPITCH - VPR * EPV; }
             }
+            if (BPS == 2) bad = seen & ~(((1u << g.depth) - 1u) * 0x00010001u);
         } else {                                   // picture edge: zero outside (ffv2enc.c:69-71), mask per sample
 #pragma unroll
             for (int it = 0; it < PER_LANE; it++) {
@@ -289,8 +296,8 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
                         uint32_t o[8];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            o[2 * k]     = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u) << sh) & m;
-                            o[2 * k + 1] = pk_sub2048(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u) << sh) & m;
+                            o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul) & m;
+                            o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul) & m;
                         }
                         dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                         dst[1] = make_int4(o[4], o[5], o[6], o[7]);
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             bad |= w[k] & himask;                 // w is 0 where the vector is outside
-                            o[k] = pk_sub2048(w[k] << sh) & m;
+                            o[k] = pk_level_shift(w[k], lsmul) & m;
                         }
                         dst[0] = make_int4(o[0], o[1], o[2], o[3]);
                     }
@@ -707,9 +714,7 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
 
 hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
 {
-    const long long total = (long long)a.nframes * a.g.nblk;
-    const long long chunk = (total + 7) / 8;
-    const dim3 grid((unsigned)(chunk * 8)), block(64);
+    const dim3 grid((unsigned)((a.g.nblk + 7) / 8 * 8), (unsigned)a.nframes), block(64);
     const bool wc = a.coef != nullptr;
     if (a.g.bytes_per_sample == 1) {
         if (wc) hipLaunchKernelGGL((ffv2_tstage_kernel<1, true>),  grid, block, 0, s, a);

@@ -153,21 +153,54 @@ __device__ __forceinline__ int wave_iscan(int v)
     return v;
 }
 
-// 64-bit per-lane sums are scanned as a 24-bit low part and a high part: both stay
-// below 2^31 over 64 lanes (|coef| < 2^21, at most 32 squares per lane).
-struct Scan64 {
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+// 64-bit lane values a, b -> lanes 0..31: a[l] + a[l+32], lanes 32..63: b[l-32] + b[l]
+__device__ __forceinline__ unsigned long long fold32(unsigned long long a, unsigned long long b)
+{
+    const auto l = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((uint32_t)(a >> 32), (uint32_t)(b >> 32), false, false);
+    return (((unsigned long long)h[0] << 32) | l[0]) + (((unsigned long long)h[1] << 32) | l[1]);
+}
+// rows of 16 lanes: (a0+a1 | b0+b1 | a2+a3 | b2+b3)
+__device__ __forceinline__ unsigned long long fold16(unsigned long long a, unsigned long long b)
+{
+    const auto l = __builtin_amdgcn_permlane16_swap((uint32_t)a, (uint32_t)b, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((uint32_t)(a >> 32), (uint32_t)(b >> 32), false, false);
+    return (((unsigned long long)h[0] << 32) | l[0]) + (((unsigned long long)h[1] << 32) | l[1]);
+}
+
+// Inclusive prefix sums inside each row of 16 lanes.  The 64-bit values (< 2^49: up to four
+// lanes' worth of at most 32 squares of |coef| < 2^21) are scanned as a 24-bit low part and
+// a high part, both of which stay below 2^31 over 16 lanes.
+struct RowScan {
     int lo, hi;
-    __device__ __forceinline__ void run(unsigned long long a)
+    __device__ __forceinline__ explicit RowScan(unsigned long long a)
     {
-        lo = wave_iscan((int)(a & 0xffffffull));
-        hi = wave_iscan((int)(a >> 24));
+        lo = (int)(a & 0xffffffull);
+        hi = (int)(a >> 24);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int &v = k ? hi : lo;
+            v += dpp_mov<0x111>(v);
+            v += dpp_mov<0x112>(v);
+            v += dpp_mov<0x114>(v);
+            v += dpp_mov<0x118>(v);
+        }
     }
-    __device__ __forceinline__ long long at(int l) const       // inclusive sum of lanes 0..l, wave-uniform
-    {
-        const unsigned long long h = (unsigned)__builtin_amdgcn_readlane(hi, l);
-        const unsigned long long w = (unsigned)__builtin_amdgcn_readlane(lo, l);
-        return (long long)((h << 24) + w);
-    }
+};
+
+// which band total a lane ends up with after the transposed reduction of phase F:
+// low nibble = band, high nibble = source (0 acc0 prefix, 1 prefix - prefix[lane-2],
+// 2 prefix - prefix[lane-8], 3 Y2 moved down one lane, 4 Y1 moved down two lanes); 0xff = none
+__device__ const uint8_t LANE_BAND[64] = {
+    0xff, 0xff, 0xff, 0x00, 0xff, 0x11, 0xff, 0x12, 0xff, 0xff, 0xff, 0xff, 0xff, 0x49, 0x37, 0x23,
+    0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x04, 0xff, 0xff, 0xff, 0xff, 0xff, 0x4b, 0xff, 0x25,
+    0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x4a, 0x38, 0xff,
+    0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x4c, 0x36, 0xff,
 };
 
 constexpr int RPITCH = 69;   // dwords per row of the raster buffer: the scan-order gather is
@@ -212,6 +245,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 #pragma unroll
     for (int i = 0; i < 8; i++)
         lut[i] = reinterpret_cast<const uint4 *>(a.lds_scan)[i * 64 + lane];
+    const int lane_info = LANE_BAND[lane];
 
     // ---- phase A: coalesced 16-byte reads of the 96x96 halo tile -> int16 LDS ----
     {
@@ -456,59 +490,60 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
             acc[2 + b] = s;
         }
     }
-    long long en[FFV2_NUM_BANDS];
+    // Band energies by a transposed reduction: every fold halves the number of registers
+    // while it sums across lanes, and each band total ends in a lane of its own, which then
+    // codes the gain - no SGPR round trip.
+    //   Y1 rows (16 lanes each) = acc2 | acc4 | acc3 | acc5     -> bands 9, 11, 10, 12
+    //   Y2 rows                 = acc1 rows 0+1 | - | acc1 rows 2+3 | acc0 rows 2+3 -> bands 7, -, 8, 6
+    //   Y3                      = acc0 (rows 0 and 1: prefix sums give bands 0..5)
+    unsigned long long my;
     {
-        Scan64 s;
-        s.run(acc[0]);
-        constexpr int BL[7] = { 3, 5, 7, 15, 23, 31, 63 };   // last lane of bands 0..6 within j = 0
-        long long prev = 0;
-#pragma unroll
-        for (int b = 0; b < 7; b++) {
-            const long long cur = s.at(BL[b]);
-            en[b] = cur - prev;
-            prev = cur;
-        }
-        s.run(acc[1]);
-        en[7] = s.at(31);
-        en[8] = s.at(63) - en[7];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            s.run(acc[2 + b]);
-            en[9 + b] = s.at(63);
-        }
+        const unsigned long long y1 = fold16(fold32(acc[2], acc[3]), fold32(acc[4], acc[5]));
+        const unsigned long long y2 = fold16(acc[1], acc[0]);
+        const RowScan s1(y1), s2(y2), s3(acc[0]);
+        // lane <- lane-2 / lane-8 differences of the acc0 prefix, lane <- lane+2 / lane+1 moves
+        const int d2lo = s3.lo - dpp_mov<0x112>(s3.lo), d2hi = s3.hi - dpp_mov<0x112>(s3.hi);
+        const int d8lo = s3.lo - dpp_mov<0x118>(s3.lo), d8hi = s3.hi - dpp_mov<0x118>(s3.hi);
+        const int m1lo = dpp_mov<0x102>(s1.lo), m1hi = dpp_mov<0x102>(s1.hi);
+        const int m2lo = dpp_mov<0x101>(s2.lo), m2hi = dpp_mov<0x101>(s2.hi);
+        const int sel = lane_info >> 4;
+        int lo = s3.lo, hi = s3.hi;
+        if (sel == 1) { lo = d2lo; hi = d2hi; }
+        if (sel == 2) { lo = d8lo; hi = d8hi; }
+        if (sel == 3) { lo = m2lo; hi = m2hi; }
+        if (sel == 4) { lo = m1lo; hi = m1hi; }
+        my = (unsigned long long)(((long long)hi << 24) + lo);
     }
-    const int c0 = __builtin_amdgcn_readlane(x[0], 0);
-
-    long long my = 0;
-#pragma unroll
-    for (int b = 0; b < 13; b++) my = lane == b ? en[b] : my;
-    if (a.energy && lane < 13)
-        a.energy[((size_t)f * g.nblk + bp) * FFV2_NUM_BANDS + lane] = my;
+    const bool has_band = lane_info != 0xff;
+    const int band = lane_info & 15;
+    if (a.energy && has_band)
+        a.energy[((size_t)f * g.nblk + bp) * FFV2_NUM_BANDS + band] = (long long)my;
 
     if (a.codes) {
-        // lanes 0..12: band gains; lane 13: the "DC" slot; the reference's last band
-        // also squares the int32 that follows temp2[] (phantom W)
-        if (lane == 12 && a.W) {
+        // band lanes: gains; lane 0: the "DC" slot (it holds coding index 0); the reference's
+        // last band also squares the int32 that follows temp2[] (phantom W)
+        if (band == 12 && has_band && a.W) {
             const long long w = a.W[(size_t)f * g.nblk + bp];
-            my += w * w;
+            my += (unsigned long long)(w * w);
         }
         bool oot = false;
         uint32_t val = 0;
         int nb = 0;
-        if (lane < 13) {
-            val = coded_gain(my, a.gain_thr, a.gain_n, oot);
+        if (has_band) {
+            val = coded_gain((long long)my, a.gain_thr, a.gain_n, oot);
             nb = golomb_len(val);
-        } else if (lane == 13) {
+        } else if (lane == 0) {
+            const int c0 = x[0];
             val = (uint32_t)c0;
             const uint32_t mag = c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0;
             nb = golomb_len(mag) + (c0 != 0);
         }
-        nb = __builtin_amdgcn_readlane(wave_iscan(nb), 63);
+        nb = wave_iscan(nb);                                   // lane 63: bits of the whole record
         uint32_t *rec = a.codes + ((size_t)f * g.nblk + bp) * FFV2_CODES_PER_BP;
-        if (lane < 13)       rec[1 + lane] = val;
-        else if (lane == 13) rec[0] = val;
-        else if (lane == 14) { rec[14] = (uint32_t)nb; a.bitcnt[(size_t)f * g.nblk + bp] = (uint32_t)nb; }
-        else if (lane == 15) rec[15] = 0;
+        if (has_band)        rec[1 + band] = val;
+        else if (lane == 0)  rec[0] = val;
+        else if (lane == 63) { rec[14] = (uint32_t)nb; a.bitcnt[(size_t)f * g.nblk + bp] = (uint32_t)nb; }
+        else if (lane == 1)  rec[15] = 0;
         if (__any(oot) && lane == 0)
             atomicMin(&a.status[f], -34);
     }

@@ -5,7 +5,7 @@ CC      ?= gcc
 HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-strict-aliasing -ffp-contract=off -Wall
 CSRC     = ffmpeg_ffv2_amd/csrc
 LIB      = ffmpeg_ffv2_amd/libffv2amd.so
-OBJS     = $(CSRC)/ffv2_kernels.o $(CSRC)/ffv2_pvq.o $(CSRC)/ffv2_inverse.o $(CSRC)/ffv2_capi.o $(CSRC)/ffv2enc_amd.o
+OBJS     = $(CSRC)/ffv2_kernels.o $(CSRC)/ffv2_pvq.o $(CSRC)/ffv2_inverse.o $(CSRC)/ffv2_capi.o $(CSRC)/ffv2enc_amd.o $(CSRC)/ffv2mkv.o
 
 all: $(LIB) examples/ffv2enc_cli oracle
 
@@ -16,6 +16,9 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/ffv2_kernels.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/ffv2_capi.o: $(CSRC)/ffv2_capi.cpp $(CSRC)/ffv2_kernels.h include/ffv2_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/ffv2mkv.o: $(CSRC)/ffv2mkv.c include/ffv2_amd_mkv.h
+	$(CC) -O2 -fPIC -std=gnu11 -Wall -Iinclude -c $< -o $@
+
 $(CSRC)/ffv2enc_amd.o: $(CSRC)/ffv2enc_amd.c include/ffv2_amd.h include/ffv2_amd_codec.h
 	$(CC) -O2 -fPIC -std=gnu11 -Wall -Iinclude -c $< -o $@
 

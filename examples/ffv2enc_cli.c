@@ -7,6 +7,8 @@
  *
  *   ffv2enc_cli WIDTH HEIGHT PIX_FMT IN.yuv OUT.ffv2 [QP] [HIP_DEVICE]
  *   PIX_FMT: gray | yuv444p | yuv444p10le | yuv444p12le | gbrp | gbrp10le | gbrp12le
+ * An output name ending in ".mkv" selects the Matroska writer (include/ffv2_amd_mkv.h,
+ * "V_FFV2", 25 frames per second) instead of the back-to-back packet stream.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +16,7 @@
 
 #include "ffv2_amd.h"
 #include "ffv2_amd_codec.h"
+#include "ffv2_amd_mkv.h"
 
 static int parse_fmt(const char *s, int *planes, int *bps)
 {
@@ -43,8 +46,12 @@ int main(int argc, char **argv)
     ctx.hip_device = argc > 7 ? atoi(argv[7]) : 0;
     if (ctx.pix_fmt < 0) { fprintf(stderr, "unsupported pix_fmt %s (the encoder takes 4:4:4 planar only)\n", argv[3]); return 2; }
     FILE *in = strcmp(argv[4], "-") ? fopen(argv[4], "rb") : stdin;
-    FILE *out = strcmp(argv[5], "-") ? fopen(argv[5], "wb") : stdout;
-    if (!in || !out) { perror("open"); return 1; }
+    const size_t olen = strlen(argv[5]);
+    const int as_mkv = olen > 4 && !strcmp(argv[5] + olen - 4, ".mkv");
+    FILE *out = as_mkv ? NULL : (strcmp(argv[5], "-") ? fopen(argv[5], "wb") : stdout);
+    ffv2amd_mkv *mkv = NULL;
+    if (as_mkv && ffv2amd_mkv_open(&mkv, argv[5], ctx.width, ctx.height, 25, 1) < 0) { perror("open"); return 1; }
+    if (!in || (!out && !mkv)) { perror("open"); return 1; }
     int ret = ffv2amd_codec_init(&ctx);
     if (ret < 0) { fprintf(stderr, "init failed: %d\n", ret); return 1; }
 
@@ -64,14 +71,16 @@ int main(int argc, char **argv)
         fr.pts = nframes;
         ret = ffv2amd_codec_encode2(&ctx, &pkt, &fr, &got);
         if (ret < 0 || !got) { fprintf(stderr, "encode2 failed on frame %ld: %d\n", nframes, ret); break; }
-        fwrite(pkt.data, 1, (size_t)pkt.size, out);
+        if (mkv) ret = ffv2amd_mkv_write_packet(mkv, pkt.data, (size_t)pkt.size, pkt.pts);
+        else     fwrite(pkt.data, 1, (size_t)pkt.size, out);
         nbytes += (size_t)pkt.size;
         ffv2amd_packet_unref(&pkt);
         nframes++;
     }
     ffv2amd_codec_close(&ctx);
     free(buf);
-    if (out != stdout) fclose(out);
+    if (mkv) { const int r2 = ffv2amd_mkv_close(mkv); if (ret >= 0) ret = r2; }
+    else if (out != stdout) fclose(out);
     fprintf(stderr, "%ld frames, %zu bytes\n", nframes, nbytes);
     return ret < 0 ? 1 : 0;
 }

@@ -14,6 +14,8 @@ EXPORTS = [
     "ffv2amd_encoder_set_pipelined", "ffv2amd_encoder_flush", "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device", "ffv2amd_inverse_tstage_device",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
+    # Matroska wire step (ffv2mkv.c)
+    "ffv2amd_mkv_open", "ffv2amd_mkv_write_packet", "ffv2amd_mkv_close",
 ]
 
 ERRORS = {-22: "EINVAL", -12: "ENOMEM", -5: "EIO (HIP device/runtime)", -28: "ENOSPC",

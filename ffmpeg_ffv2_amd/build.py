@@ -10,7 +10,7 @@ CSRC = os.path.join(PKG, "csrc")
 SO = os.path.join(PKG, "libffv2amd.so")
 
 HIP_SOURCES = ["ffv2_kernels.hip", "ffv2_pvq.hip", "ffv2_inverse.hip", "ffv2_capi.cpp"]
-C_SOURCES = ["ffv2enc_amd.c"]
+C_SOURCES = ["ffv2enc_amd.c", "ffv2mkv.c"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-strict-aliasing",
             "-ffp-contract=off", "-Wall"]
 
@@ -28,7 +28,7 @@ def needs_build():
     t = os.path.getmtime(SO)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith("gen")]
     deps += [os.path.join(CSRC, "gen", f) for f in os.listdir(os.path.join(CSRC, "gen"))]
-    deps.append(os.path.join(ROOT, "include", "ffv2_amd.h"))
+    deps += [os.path.join(ROOT, "include", h) for h in ("ffv2_amd.h", "ffv2_amd_codec.h", "ffv2_amd_mkv.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 

@@ -488,7 +488,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (pipe && e->evE_valid[pb])                  // the E-stage two calls ago read this hand-off buffer
         HIPCHK(hipStreamWaitEvent(s, e->evE[pb], 0));
     HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, s));
-    if (!pipe) HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, s));
+    // the packet buffers are cleared by the T-stage itself (FFV2TStageArgs::zero)
 
     FFV2TStageArgs a{};
     a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
@@ -496,6 +496,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
     a.status = status;
     a.coef = e->coef_sink;
+    a.zero = (uint32_t *)d_packets; a.zero_stride_dw = (uint32_t)(packet_stride / 4);
     ffv2amd_encoder::EvTriple *ev = nullptr;
     if (e->profiling) {
         if (e->ev_used == e->ev_pool.size()) {
@@ -518,7 +519,6 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (pipe) {
         HIPCHK(hipEventRecord(e->evT[pb], s));
         HIPCHK(hipStreamWaitEvent(se, e->evT[pb], 0));
-        HIPCHK(hipMemsetAsync(d_packets, 0, packet_stride * (size_t)nframes, se));
     }
     if (ev) HIPCHK(hipEventRecord(ev->d, se));
 

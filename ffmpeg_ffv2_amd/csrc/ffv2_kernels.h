@@ -31,6 +31,8 @@ struct FFV2TStageArgs {
     int gain_n;                       // entries in gain_thr
     const uint16_t *lds_scan;         // [8][64][8] byte offsets into the LDS raster, see ffv2_capi.cpp
     int32_t *status;                  // [nframes] sticky per-frame error
+    uint32_t *zero;                   // optional: packet buffers the E-stage ORs into, cleared here (saves a memset launch)
+    uint32_t zero_stride_dw;          // dwords per frame in `zero`
 };
 
 struct FFV2EStageArgs {
@@ -38,7 +40,7 @@ struct FFV2EStageArgs {
     int nframes;
     const uint32_t *codes;            // [nframes][nblk][16]
     const uint32_t *bitoff;           // [nframes][nblk] raw bits per block-plane (T-stage bitcnt)
-    uint8_t  *packets;                // [nframes][packet_stride], zeroed by the caller
+    uint8_t  *packets;                // [nframes][packet_stride], zeroed beforehand (FFV2TStageArgs::zero)
     size_t    packet_stride;
     uint32_t *sizes;                  // [nframes]
     int32_t  *status;                 // [nframes]

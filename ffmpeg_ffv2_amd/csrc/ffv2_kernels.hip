@@ -612,6 +612,15 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         for (int j = 0; j < 16; j++)
             cp[j * 64 + lane] = make_int4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
     }
+    // this block-plane's share of the frame's packet buffer, cleared for the E-stage's atomic ORs
+    if (a.zero) {
+        const uint32_t per = (a.zero_stride_dw + (uint32_t)g.nblk - 1u) / (uint32_t)g.nblk;
+        uint32_t *z = a.zero + (size_t)f * a.zero_stride_dw;
+        for (uint32_t d = (uint32_t)lane; d < per; d += 64) {
+            const uint32_t i = (uint32_t)bp * per + d;
+            if (i < a.zero_stride_dw) z[i] = 0;
+        }
+    }
     FFV2_PHASE_MARK(7);
     FFV2_PHASE_END;
 }

@@ -410,7 +410,7 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     std::call_once(g_thr_once, build_gain_table);
     // phase-F scan table: [i][lane][e] -> byte offset of coding index
     // q = 256*(2i + e/4) + 4*lane + e%4 in the raster buffer (row pitch 69 dwords)
-    static uint16_t lds_scan[4096];
+    uint16_t lds_scan[4096];                                  // per call: create() may run concurrently (INIT_THREADSAFE)
     for (int i = 0; i < 8; i++)
         for (int l = 0; l < 64; l++)
             for (int e = 0; e < 8; e++) {

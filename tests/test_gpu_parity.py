@@ -431,3 +431,34 @@ def test_avcodec_shaped_shim(oracle):
     assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0 and not ctx.priv_data
     bad = Ctx(320, 240, 0, 0, 0, None)                     # yuv420p is not accepted (ffv2enc.c:596-601)
     assert lib.ffv2amd_codec_init(C.byref(bad)) == -22
+
+
+def test_two_contexts_on_two_host_threads(oracle):
+    """AVCodec contract (SURVEY.md 8b 'Threading'): init may run concurrently for different contexts and
+    each context is driven by exactly one thread.  Two threads, two encoders, interleaved calls."""
+    import threading
+    results, errors = {}, []
+
+    def worker(idx, fmt, P, H, W, depth):
+        try:
+            enc = _enc(W, H, fmt)
+            out = []
+            for n in range(6):
+                fr = synth.make("S2" if (n + idx) % 2 else "S1", 10 * idx + n, P, H, W, depth)
+                out.append((fr, enc.encode2(fr)))
+            enc.close()
+            results[idx] = (fmt, out)
+        except Exception as exc:              # surfaced below: an exception in a thread must fail the test
+            errors.append(exc)
+
+    ts = [threading.Thread(target=worker, args=(0, "yuv444p10le", 3, 240, 320, 10)),
+          threading.Thread(target=worker, args=(1, "gray", 1, 300, 200, 8))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for idx in (0, 1):
+        fmt, out = results[idx]
+        for fr, pk in out:
+            assert pk == oracle.encode(fr, fmt)

@@ -462,3 +462,29 @@ def test_two_contexts_on_two_host_threads(oracle):
         fmt, out = results[idx]
         for fr, pk in out:
             assert pk == oracle.encode(fr, fmt)
+
+
+def test_batch_encode_is_graph_capturable(oracle):
+    """ffv2amd_encode_batch_device only enqueues (one memset, two kernels): it can be captured into a
+    hipGraph on the caller's stream and replayed on new frame contents in the same buffers."""
+    import torch
+    W, H, fmt, P, depth, F = 320, 240, "yuv444p10le", 3, 10, 3
+    enc = _enc(W, H, fmt, max_batch=F)
+    fr = np.stack([synth.make("S2", n, P, H, W, depth) for n in range(F)])
+    d = enc.upload(fr)
+    out = enc.alloc_packets(F)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        enc.encode_batch_device(d, out=out, stream=s.cuda_stream)       # warm-up outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        enc.encode_batch_device(d, out=out, stream=torch.cuda.current_stream().cuda_stream)
+    for seed in (0, 7):
+        fr2 = np.stack([synth.make("S1" if seed else "S2", 20 + seed + n, P, H, W, depth) for n in range(F)])
+        d.copy_(enc.upload(fr2))
+        out[0].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert enc.collect(*out) == [oracle.encode(fr2[n], fmt) for n in range(F)]
+    enc.close()

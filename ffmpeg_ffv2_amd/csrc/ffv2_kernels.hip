@@ -469,31 +469,42 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     __syncthreads();
     FFV2_PHASE_MARK(2);
 
-    // ---- phase C: vertical lapping on the two horizontal seams (columns in parallel) ----
-#pragma unroll 1
-    for (int seam = 0; seam < 2; seam++) {
-        if (seam == 0 ? !seamT : !seamB) continue;           // wave-uniform
-        const int rb = seam == 0 ? 0 : 64;
-        int x[32];
+    // ---- phase C: vertical lapping on the two horizontal seams, lane = column.  The lapped
+    // rows stay in registers: they are this column's inputs to phase D, which has the same
+    // lane = column orientation, so nothing goes back through LDS. ----
+    int x[64];
+    {
+        const int16_t *colp = tile + 16 + lane;
+        if (seamT) {                                         // wave-uniform
+            int t[32];
 #pragma unroll
-        for (int k = 0; k < 32; k++) x[k] = tile[(rb + k) * TPITCH + 16 + lane];
-        lap32(x);
-        if (seam == 0) {
+            for (int k = 0; k < 32; k++) t[k] = colp[k * TPITCH];
+            lap32(t);
 #pragma unroll
-            for (int k = 0; k < 16; k++) tile[(16 + k) * TPITCH + 16 + lane] = (int16_t)x[16 + k];
+            for (int k = 0; k < 16; k++) x[k] = t[16 + k];                  // tile rows 16..31
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) tile[(64 + k) * TPITCH + 16 + lane] = (int16_t)x[k];
+            for (int k = 0; k < 16; k++) x[k] = colp[(16 + k) * TPITCH];
         }
+        if (seamB) {
+            int t[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) t[k] = colp[(64 + k) * TPITCH];
+            lap32(t);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[48 + k] = t[k];                  // tile rows 64..79
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[48 + k] = colp[(64 + k) * TPITCH];
+        }
+#pragma unroll
+        for (int k = 16; k < 48; k++) x[k] = colp[(16 + k) * TPITCH];      // rows 32..63: untouched by the seams
     }
-    __syncthreads();
     FFV2_PHASE_MARK(3);
 
     // ---- phase D: column transforms (lane = column), then transpose through LDS ----
-    int x[64];
 #pragma unroll
     for (int k = 0; k < 64; k++) {
-        x[k] = tile[(16 + k) * TPITCH + 16 + lane];
         // keep the 16-bit provenance from the optimiser: with known-bits it rewrites
         // __mul24 into a plain 32-bit multiply and then selects v_mul_lo_u32
         asm("" : "+v"(x[k]));

@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def md5(b):
@@ -134,3 +135,35 @@ def test_oracle_round_trip_is_exact(oracle):
             fr = synth.make(kind, 2, P, H, W, depth)
             coef, _ = oracle.tstage(fr, fmt)
             assert np.array_equal(oracle.inverse_tstage(coef, fmt, P, H, W, depth), fr)
+
+
+def test_column_pass_multiplies_cannot_overflow_int32():
+    """The HIP column pass evaluates (a*K + R) >> S as the high dword of a 64-bit product where K < 2^(S-1)
+    (ffv2_kernels.hip, FFV2_MULRS_NOOVF).  That equals the reference's wrapping int32 arithmetic only if a*K + R
+    never leaves int32: bound every multiply operand of the network by its L1 gain times the largest lapped sample
+    (23 100) plus accumulated rounding, as tools/ir_bounds.py does."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ir_bounds", os.path.join(ROOT, "tools", "ir_bounds.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mul_ops, out_l1 = mod.analyse(os.path.join(ROOT, "tools", "ir", "fdct64_ir.json"))
+    assert len(mul_ops) == 201 and abs(out_l1 - 8.0) < 1e-9
+    assert all((l1 * 23100.0 + e) * K + R < 2 ** 31 for (l1, e, K, R, S) in mul_ops)
+    assert sum(1 for (l1, e, K, R, S) in mul_ops if K < (1 << (S - 1))) == 73
+    # and the 24-bit multiply of the row pass sees operands below 2^23
+    assert max(l1 for (l1, e, K, R, S) in mul_ops) * 23100.0 * out_l1 < 2 ** 23
+
+
+def test_lapped_samples_fit_int16(oracle):
+    """The HIP T-stage stages the level-shifted, lapped samples as int16 in LDS.  The 32-tap pre-filter is linear
+    up to rounding: its largest output L1 gain (measured on scaled impulses) bounds |H| and |H o V| for the
+    level-shifted 12-bit range |x| <= 2048, with room for the rounding of the two passes."""
+    scale = 1 << 18
+    gains = np.zeros((32, 32))
+    for i in range(32):
+        x = np.zeros(32, np.int32)
+        x[i] = scale
+        gains[:, i] = np.asarray(oracle.lap32(x[None])[0], dtype=np.float64) / scale
+    l1 = np.abs(gains).sum(axis=1).max()
+    assert 3.3 < l1 < 3.4
+    assert 2048 * l1 * l1 + 64 < 32767

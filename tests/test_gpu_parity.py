@@ -212,7 +212,8 @@ def test_random_geometries(oracle):
 
 
 @pytest.mark.parametrize("fmt,P,H,W,depth", [("gray", 1, 1, 1, 8), ("yuv444p", 3, 64, 8192, 8), ("gray", 1, 8192, 64, 8),
-                                             ("yuv444p10le", 3, 65, 4097, 10), ("gbrp12le", 3, 2, 3000, 12)])
+                                             ("yuv444p10le", 3, 65, 4097, 10), ("gbrp12le", 3, 2, 3000, 12),
+                                             ("gray", 1, 1, 16384, 8), ("gray", 1, 4097, 1, 8), ("yuv444p12le", 3, 63, 65, 12)])
 def test_extreme_geometries(oracle, fmt, P, H, W, depth):
     enc = _enc(W, H, fmt)
     fr = synth.noise(9, P, H, W, depth)

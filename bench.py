@@ -200,6 +200,17 @@ def main():
                           % (n_done, F, W, H, fmt),
                 "host_cores_available": os.cpu_count(),
                 "gpu_packets_match_cpu": bool(ok)}
+            # informational: frames are independent, so the CPU scales by running one encoder per
+            # core; one frame per thread on this box's CPU share, a few seconds
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as pool:       # ctypes releases the GIL inside the oracle
+                list(pool.map(lambda i: oracle.encode(host_frames[i % F], fmt), range(nthr)))
+            tall = time.perf_counter() - c0
+            result["cpu_baseline"]["all_cores"] = {"value": round(nthr * W * H / tall / 1e6, 1), "unit": "Mpix/s",
+                                                   "cores": nthr, "sample": "one 4K frame per thread" if W == 3840
+                                                   else "one frame per thread"}
             if not ok:
                 result["error"] = "GPU packets differ from the CPU oracle"
         print(json.dumps(result))

@@ -149,7 +149,8 @@ __device__ __forceinline__ void lap32(int (&x)[32])
 
 __device__ __forceinline__ int lo16(uint32_t w) { return (int)(w << 16) >> 16; }
 __device__ __forceinline__ int hi16(uint32_t w) { return (int)w >> 16; }
-__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+// low halves of two registers into one dword: one v_perm_b32 (bytes 0,1 of lo; bytes 0,1 of hi)
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
 
 // Coded band gain, bit-identical to the host's
 //   (uint32)(float)pow((double)(sqrtf((float)e) + FLT_EPSILON), (double)(1.0f/1.5f))

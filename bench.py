@@ -36,6 +36,7 @@ CONFIGS = {
     "C5": (7680, 4320, "yuv444p12le", 12),
 }
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PREROLL_GROUP, PREROLL_MAX = 10, 150
 
 
 def main():
@@ -51,6 +52,7 @@ def main():
                     help="E-stage of step n on the encoder's own stream, overlapping the T-stage of step n+1 "
                          "(measured: ~1 % more Mpix/s, but the T-stage timing then includes the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-preroll", action="store_true", help="skip the untimed clock-settling pre-roll")
     ap.add_argument("--qp", type=int, default=0,
                     help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()
@@ -115,6 +117,24 @@ def main():
         return
     for i in range(args.warmup):
         enc.encode_batch_device(d_frames, out=outs[i & 1], stream=stream)
+    # Clock-settling pre-roll, untimed and independent of --warmup: the chip's power management
+    # needs ~50-100 back-to-back launches before the T-stage time stops moving (480 -> 580 -> 400 us
+    # on C3).  Groups of PREROLL_GROUP launches until three consecutive group means agree within
+    # 1 %, at most PREROLL_MAX launches; the count is disclosed as "preroll_launches".
+    preroll = 0
+    if not args.no_preroll:
+        enc.profile(True)
+        enc.profile_read()
+        hist = []
+        while preroll < PREROLL_MAX:
+            for i in range(PREROLL_GROUP):
+                enc.encode_batch_device(d_frames, out=outs[i & 1], stream=stream)
+            preroll += PREROLL_GROUP
+            t_ms, _, n = enc.profile_read()
+            hist.append(t_ms / max(n, 1))
+            if len(hist) >= 3 and max(hist[-3:]) <= 1.01 * min(hist[-3:]):
+                break
+        enc.profile(False)
     barrier()
     enc.profile(True)
     enc.profile_read()
@@ -159,6 +179,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preroll_launches": preroll,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

@@ -390,6 +390,7 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     in.row_pitch = align_up((size_t)width * bps, 128);
     in.plane_stride = align_up(in.row_pitch * height, 256);
     in.frame_stride = in.plane_stride * planes;
+    if (in.plane_stride >= ((size_t)1 << 32)) return (delete e, FFV2AMD_ERR_INVAL);   // 32-bit in-plane offsets in the kernels
     in.tstage_bytes_per_frame = (size_t)planes * width * height * bps +
                                 (size_t)planes * (64 * in.num_sb_x) * (64 * in.num_sb_y) * 4;
 
@@ -406,6 +407,8 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     g.width = width; g.height = height; g.depth = depth; g.planes = planes; g.bytes_per_sample = bps;
     g.nsx = in.num_sb_x; g.nsy = in.num_sb_y; g.nblk = in.block_planes;
     g.row_pitch = in.row_pitch; g.plane_stride = in.plane_stride; g.frame_stride = in.frame_stride;
+    g.inv_planes = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)planes + 1);
+    g.inv_nsx = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)g.nsx + 1);
 
     std::call_once(g_thr_once, build_gain_table);
     // phase-F scan table: [i][lane][e] -> byte offset of coding index

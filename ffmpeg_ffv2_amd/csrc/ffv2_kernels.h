@@ -16,6 +16,7 @@ struct FFV2Geom {
     int width, height, depth, planes, bytes_per_sample;
     int nsx, nsy, nblk;               // nblk = nsx*nsy*planes
     size_t row_pitch, plane_stride, frame_stride;
+    uint32_t inv_planes, inv_nsx;     // floor(2^32/d)+1 for d = planes, nsx (unused when d == 1)
 };
 
 struct FFV2TStageArgs {

@@ -257,252 +257,17 @@ constexpr int RPITCH = 69;   // dwords per row of the raster buffer: the scan-or
                              // ~2.5x conflict cycles here vs 10.8x at 65 (tools: LDS bank model)
 static_assert(64 * RPITCH * 4 <= LDS_BYTES, "raster buffer must fit in the tile");
 
-template <int BPS, bool WRITE_COEF>
-__global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs a)
+// Back half of the T-stage for one 64x64 block-plane whose lapped samples sit in x[] with
+// lane = column, x[k] = row k: phases D (column DCT + transpose), E (row DCT), F (scan-order
+// gather, band energies, gains, record) and the coefficient stores.  Shared by the one-block
+// kernel and the column-walking kernel.  `xb` is the workgroup's LDS, free for reuse on entry
+// once the caller's barrier has passed.
+template <bool WRITE_COEF>
+__device__ __forceinline__ void tstage_back_half(int (&x)[64], const uint4 (&lut)[8], int *xb,
+                                                 const FFV2TStageArgs &a, const int f, const int bp,
+                                                 const int lane, const int lane_info)
 {
-    __shared__ int4 lds_raw[LDS_BYTES / 16];
-    int16_t  *tile = reinterpret_cast<int16_t *>(lds_raw);
-    int      *xb   = reinterpret_cast<int *>(lds_raw);
-
     const FFV2Geom &g = a.g;
-    const int lane = threadIdx.x;
-    FFV2_PHASE_BEGIN
-
-    // XCD-aware block id: workgroups b and b+8 share an XCD (round-robin dispatch; gridDim.x
-    // is a multiple of 8 and blockIdx.y = frame), so give each XCD one contiguous run of the
-    // frame's block-planes -> neighbouring tiles, which share their 32-sample halos, meet in
-    // the same L2.  All of it 32-bit and scalar: no 64-bit divide on the way in.
-    const uint32_t chunk = gridDim.x >> 3;
-    const uint32_t ubp = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
-    if (ubp >= (uint32_t)g.nblk) return;
-    const int f   = (int)blockIdx.y;
-    const int bp  = (int)ubp;
-    const int sb  = (int)(ubp / (uint32_t)g.planes);
-    const int p   = bp - sb * g.planes;
-    const int sby = (int)((uint32_t)sb / (uint32_t)g.nsx);
-    const int sbx = sb - sby * g.nsx;
-
-    const uint8_t *plane = a.frames + (size_t)f * g.frame_stride + (size_t)p * g.plane_stride;
-    const int sh = 12 - g.depth;
-    const int x_org = sbx * 64 - 16, y_org = sby * 64 - 16;
-    const bool seamL = sbx > 0, seamR = sbx + 1 < g.nsx;
-    const bool seamT = sby > 0, seamB = sby + 1 < g.nsy;
-    const int grid_h = g.nsy * 64;
-
-    // scan table for phase F, fetched now so that nothing but stores is outstanding
-    // there: [i][lane] 16-byte rows of 8 byte-offsets into the raster buffer, entry e of
-    // row i is coding index q = 256*(2i + e/4) + 4*lane + e%4
-    uint4 lut[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        lut[i] = reinterpret_cast<const uint4 *>(a.lds_scan)[i * 64 + lane];
-    const int lane_info = LANE_BAND[lane];
-
-    FFV2_PHASE_MARK(0);
-    // ---- phase A: coalesced 16-byte reads of the 96x96 halo tile -> int16 LDS ----
-    {
-        constexpr int EPV = 16 / BPS;              // samples per 16-byte vector
-        constexpr int VPR = TILE / EPV;            // vectors per tile row (6 | 12)
-        constexpr int PER_LANE = TILE * VPR / 64;  // 9 | 18
-        constexpr int RSTEP = 64 / VPR, CSTEP = 64 % VPR;   // vector index += 64  <=>  row += RSTEP, col += CSTEP
-        const bool inside = (x_org >= 0) & (x_org + TILE <= g.width) & (y_org >= 0) & (y_org + TILE <= g.height);
-        uint4 v[PER_LANE];
-        uint32_t bad = 0;
-        const uint32_t lsmul = (1u << sh) * 0x00010001u;
-        if (inside) {                              // wave-uniform: no per-sample masking needed
-            // vector index of iteration `it` is it*64 + lane.  64 = RSTEP*VPR + 4 and 3*4 is a
-            // multiple of VPR (6 | 12), so (row, column) repeat every three iterations, shifted
-            // down by 192/VPR rows: three address phases, everything else is a constant step.
-            static_assert((3 * CSTEP) % VPR == 0, "three-phase addressing");
-            constexpr int RSTEP3 = 3 * 64 / VPR;
-            uint32_t goff[3];
-            int doff3[3];
-            {
-                int r = lane / VPR, cv = lane - (lane / VPR) * VPR;
-#pragma unroll
-                for (int ph = 0; ph < 3; ph++) {
-                    goff[ph]  = (uint32_t)(y_org + r) * (uint32_t)g.row_pitch + (uint32_t)(x_org + cv * EPV) * BPS;
-                    doff3[ph] = r * TPITCH + cv * EPV;          // int16 units
-                    r += RSTEP; cv += CSTEP;
-                    if (cv >= VPR) { cv -= VPR; r++; }
-                }
-            }
-            const uint32_t gstep = RSTEP3 * (uint32_t)g.row_pitch;
-#pragma unroll
-            for (int it = 0; it < PER_LANE; it++)
-                v[it] = *reinterpret_cast<const uint4 *>(plane + (goff[it % 3] + (uint32_t)(it / 3) * gstep));
-            uint32_t seen = 0;                     // OR of every sample word: one depth test at the end
-#pragma unroll
-            for (int it = 0; it < PER_LANE; it++) {
-                const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
-                int4 *dst = reinterpret_cast<int4 *>(tile + doff3[it % 3] + (it / 3) * RSTEP3 * TPITCH);
-                if (BPS == 1) {
-                    uint32_t o[8];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul);
-                        o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul);
-                    }
-                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                    dst[1] = make_int4(o[4], o[5], o[6], o[7]);
-                } else {
-                    uint32_t o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        seen |= w[k];
-                        o[k] = pk_level_shift(w[k], lsmul);
-                    }
-                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                }
-            }
-            if (BPS == 2) bad = seen & ~(((1u << g.depth) - 1u) * 0x00010001u);
-        } else {                                   // picture edge: zero outside (ffv2enc.c:69-71), mask per sample
-#pragma unroll
-            for (int it = 0; it < PER_LANE; it++) {
-                const int vi = it * 64 + lane;
-                const int r = vi / VPR, cv = vi - r * VPR;
-                const int y = y_org + r, x0 = x_org + cv * EPV;
-                const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
-                v[it] = ok ? *reinterpret_cast<const uint4 *>(plane + (size_t)y * g.row_pitch + (size_t)x0 * BPS)
-                           : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < PER_LANE; it++) {
-                const int vi = it * 64 + lane;
-                const int r = vi / VPR, cv = vi - r * VPR;
-                const int y = y_org + r, x0 = x_org + cv * EPV;
-                const bool ok = (y >= 0) & (y < g.height) & (x0 >= 0) & (x0 < g.width);
-                const int nvalid = ok ? g.width - x0 : 0;    // samples of this vector inside the picture
-                const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
-                int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + cv * EPV);
-                if (g.width % EPV == 0) {
-                    // the picture ends on a vector boundary: a vector is inside or outside as a whole
-                    const uint32_t m = ok ? 0xffffffffu : 0u;
-                    if (BPS == 1) {
-                        uint32_t o[8];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul) & m;
-                            o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul) & m;
-                        }
-                        dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                        dst[1] = make_int4(o[4], o[5], o[6], o[7]);
-                    } else {
-                        uint32_t o[4];
-                        const uint32_t himask = ~(((1u << g.depth) - 1u) * 0x00010001u);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            bad |= w[k] & himask;                 // w is 0 where the vector is outside
-                            o[k] = pk_level_shift(w[k], lsmul) & m;
-                        }
-                        dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                    }
-                    continue;
-                }
-                if (BPS == 1) {
-                    uint32_t o[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int e0 = 2 * k, e1 = 2 * k + 1;
-                        int s0 = (int)((w[e0 >> 2] >> ((e0 & 3) * 8)) & 0xff);
-                        int s1 = (int)((w[e1 >> 2] >> ((e1 & 3) * 8)) & 0xff);
-                        s0 = e0 < nvalid ? (s0 << sh) - 2048 : 0;
-                        s1 = e1 < nvalid ? (s1 << sh) - 2048 : 0;
-                        o[k] = pack16(s0, s1);
-                    }
-                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                    dst[1] = make_int4(o[4], o[5], o[6], o[7]);
-                } else {
-                    uint32_t o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        int s0 = (int)(w[k] & 0xffff), s1 = (int)(w[k] >> 16);
-                        if (2 * k < nvalid)     bad |= (uint32_t)s0 >> g.depth;
-                        if (2 * k + 1 < nvalid) bad |= (uint32_t)s1 >> g.depth;
-                        s0 = 2 * k     < nvalid ? (s0 << sh) - 2048 : 0;
-                        s1 = 2 * k + 1 < nvalid ? (s1 << sh) - 2048 : 0;
-                        o[k] = pack16(s0, s1);
-                    }
-                    dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-        if (__any(bad != 0) && lane == 0)
-            atomicMin(&a.status[f], -34);            // FFV2AMD_ERR_RANGE
-    }
-    __syncthreads();
-    FFV2_PHASE_MARK(1);
-
-    // ---- phase B: horizontal lapping on the two vertical seams (rows in parallel) ----
-    // 96 rows x 2 seams = 192 filter instances = 3 rounds of 64 lanes.
-#pragma unroll 1
-    for (int round = 0; round < 3; round++) {
-        const int inst = round * 64 + lane;
-        const bool right = inst >= TILE;
-        const int r = right ? inst - TILE : inst;
-        const int y = y_org + r;
-        const bool act = (right ? seamR : seamL) & (y >= 0) & (y < grid_h);
-        if (__any(act)) {
-            int x[32];
-            const int4 *src = reinterpret_cast<const int4 *>(tile + r * TPITCH + (right ? 64 : 0));
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int4 w = src[q];
-                x[8 * q + 0] = lo16(w.x); x[8 * q + 1] = hi16(w.x);
-                x[8 * q + 2] = lo16(w.y); x[8 * q + 3] = hi16(w.y);
-                x[8 * q + 4] = lo16(w.z); x[8 * q + 5] = hi16(w.z);
-                x[8 * q + 6] = lo16(w.w); x[8 * q + 7] = hi16(w.w);
-            }
-            lap32(x);
-            if (act) {
-                // keep the half that lies inside this block: left seam -> taps 16..31
-                // (tile cols 16..31), right seam -> taps 0..15 (tile cols 64..79)
-                uint32_t o[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    o[k] = right ? pack16(x[2 * k], x[2 * k + 1]) : pack16(x[16 + 2 * k], x[17 + 2 * k]);
-                int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + (right ? 64 : 16));
-                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
-                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
-            }
-        }
-    }
-    __syncthreads();
-    FFV2_PHASE_MARK(2);
-
-    // ---- phase C: vertical lapping on the two horizontal seams, lane = column.  The lapped
-    // rows stay in registers: they are this column's inputs to phase D, which has the same
-    // lane = column orientation, so nothing goes back through LDS. ----
-    int x[64];
-    {
-        const int16_t *colp = tile + 16 + lane;
-        if (seamT) {                                         // wave-uniform
-            int t[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) t[k] = colp[k * TPITCH];
-            lap32(t);
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = t[16 + k];                  // tile rows 16..31
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = colp[(16 + k) * TPITCH];
-        }
-        if (seamB) {
-            int t[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) t[k] = colp[(64 + k) * TPITCH];
-            lap32(t);
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[48 + k] = t[k];                  // tile rows 64..79
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[48 + k] = colp[(64 + k) * TPITCH];
-        }
-#pragma unroll
-        for (int k = 16; k < 48; k++) x[k] = colp[(16 + k) * TPITCH];      // rows 32..63: untouched by the seams
-    }
-    FFV2_PHASE_MARK(3);
-
     // ---- phase D: column transforms (lane = column), then transpose through LDS ----
 #pragma unroll
     for (int k = 0; k < 64; k++) {
@@ -517,7 +282,6 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 #pragma unroll
     for (int v = 0; v < 64; v++) xb[lane * XPITCH + v] = x[OUTR[v]];      // tmp[64*col + v], ffv2.c:4957
     __syncthreads();
-    FFV2_PHASE_MARK(4);
 
     // ---- phase E: row transforms (lane = vertical frequency v) ----
 #pragma unroll
@@ -529,7 +293,6 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
 #pragma unroll
     for (int u = 0; u < 64; u++) xb[lane * RPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
     __syncthreads();
-    FFV2_PHASE_MARK(5);
 
     // ---- phase F: scan-order gather, band energies, gains, coalesced 16-byte stores ----
     // lane owns coding indices q = 256*j + 4*lane + k (j < 16, k < 4) -> x[4j + k].
@@ -615,8 +378,6 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         if (__any(oot) && lane == 0)
             atomicMin(&a.status[f], -34);
     }
-
-    FFV2_PHASE_MARK(6);
     // coefficients last: 16 stores of 1 KiB per wave, nothing waits on them
     if (WRITE_COEF) {
         int4 *cp = reinterpret_cast<int4 *>(a.coef + ((size_t)f * g.nblk + bp) * 4096);
@@ -633,6 +394,226 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
             if (i < a.zero_stride_dw) z[i] = 0;
         }
     }
+}
+
+template <int BPS, bool WRITE_COEF>
+__global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs a)
+{
+    __shared__ int4 lds_raw[LDS_BYTES / 16];
+    int16_t  *tile = reinterpret_cast<int16_t *>(lds_raw);
+    int      *xb   = reinterpret_cast<int *>(lds_raw);
+
+    const FFV2Geom &g = a.g;
+    const int lane = threadIdx.x;
+    FFV2_PHASE_BEGIN
+
+    // XCD-aware block id: workgroups b and b+8 share an XCD (round-robin dispatch; gridDim.x
+    // is a multiple of 8 and blockIdx.y = frame), so give each XCD one contiguous run of the
+    // frame's block-planes -> neighbouring tiles, which share their 32-sample halos, meet in
+    // the same L2.  All of it 32-bit and scalar: no 64-bit divide on the way in.
+    const uint32_t chunk = gridDim.x >> 3;
+    const uint32_t ubp = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (ubp >= (uint32_t)g.nblk) return;
+    const int f   = (int)blockIdx.y;
+    const int bp  = (int)ubp;
+    // divisions by multiply-high with the host's reciprocals (exact: dividend * divisor < 2^32)
+    const int sb  = g.planes > 1 ? (int)__umulhi(ubp, g.inv_planes) : bp;
+    const int p   = bp - sb * g.planes;
+    const int sby = g.nsx > 1 ? (int)__umulhi((uint32_t)sb, g.inv_nsx) : sb;
+    const int sbx = sb - sby * g.nsx;
+
+    const uint8_t *plane = a.frames + (size_t)f * g.frame_stride + (size_t)p * g.plane_stride;
+    const int sh = 12 - g.depth;
+    const int x_org = sbx * 64 - 16, y_org = sby * 64 - 16;
+    const bool seamL = sbx > 0, seamR = sbx + 1 < g.nsx;
+    const bool seamT = sby > 0, seamB = sby + 1 < g.nsy;
+    const int grid_h = g.nsy * 64;
+
+    // scan table for phase F, fetched now so that nothing but stores is outstanding
+    // there: [i][lane] 16-byte rows of 8 byte-offsets into the raster buffer, entry e of
+    // row i is coding index q = 256*(2i + e/4) + 4*lane + e%4
+    uint4 lut[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        lut[i] = reinterpret_cast<const uint4 *>(a.lds_scan)[i * 64 + lane];
+    const int lane_info = LANE_BAND[lane];
+
+    FFV2_PHASE_MARK(0);
+    // ---- phase A: coalesced 16-byte reads of the 96x96 halo tile -> int16 LDS ----
+    {
+        constexpr int EPV = 16 / BPS;              // samples per 16-byte vector
+        constexpr int VPR = TILE / EPV;            // vectors per tile row (6 | 12)
+        constexpr int PER_LANE = TILE * VPR / 64;  // 9 | 18
+        constexpr int RSTEP = 64 / VPR, CSTEP = 64 % VPR;   // vector index += 64  <=>  row += RSTEP, col += CSTEP
+        const bool inside = (x_org >= 0) & (x_org + TILE <= g.width) & (y_org >= 0) & (y_org + TILE <= g.height);
+        uint4 v[PER_LANE];
+        uint32_t bad = 0;
+        const uint32_t lsmul = (1u << sh) * 0x00010001u;
+        // vector index of iteration `it` is it*64 + lane.  64 = RSTEP*VPR + 4 and 3*4 is a
+        // multiple of VPR (6 | 12), so (row, column) repeat every three iterations, shifted
+        // down by 192/VPR rows: three address phases, everything else is a constant step.
+        static_assert((3 * CSTEP) % VPR == 0, "three-phase addressing");
+        constexpr int RSTEP3 = 3 * 64 / VPR;
+        uint32_t goff[3];
+        int doff3[3], row3[3], col3[3];
+        {
+            int r = lane / VPR, cv = lane - (lane / VPR) * VPR;
+#pragma unroll
+            for (int ph = 0; ph < 3; ph++) {
+                // wrapping 32-bit arithmetic: only dereferenced where the vector is inside the picture
+                goff[ph]  = (uint32_t)(y_org + r) * (uint32_t)g.row_pitch + (uint32_t)(x_org + cv * EPV) * BPS;
+                doff3[ph] = r * TPITCH + cv * EPV;          // int16 units
+                row3[ph]  = y_org + r;
+                col3[ph]  = x_org + cv * EPV;
+                r += RSTEP; cv += CSTEP;
+                if (cv >= VPR) { cv -= VPR; r++; }
+            }
+        }
+        const uint32_t gstep = RSTEP3 * (uint32_t)g.row_pitch;
+        if (inside) {                              // wave-uniform: no masking needed
+#pragma unroll
+            for (int it = 0; it < PER_LANE; it++)
+                v[it] = *reinterpret_cast<const uint4 *>(plane + (goff[it % 3] + (uint32_t)(it / 3) * gstep));
+        } else {
+            // picture edge: everything outside is 0 after the level shift (ffv2enc.c:69-71), i.e.
+            // mid-grey before it -- so vectors outside are not loaded but preset to mid-grey and
+            // then take the same conversion as the interior.  x_org is a multiple of 16, so a
+            // vector is inside or outside as a whole except the one the right edge may cut.
+            const uint32_t grey = BPS == 1 ? 0x80808080u : (2048u >> sh) * 0x00010001u;
+            bool cok[3];
+#pragma unroll
+            for (int ph = 0; ph < 3; ph++) cok[ph] = (uint32_t)col3[ph] < (uint32_t)g.width;
+#pragma unroll
+            for (int it = 0; it < PER_LANE; it++) {
+                v[it] = make_uint4(grey, grey, grey, grey);
+                const bool ok = cok[it % 3] & ((uint32_t)(row3[it % 3] + (it / 3) * RSTEP3) < (uint32_t)g.height);
+                if (ok)
+                    v[it] = *reinterpret_cast<const uint4 *>(plane + (goff[it % 3] + (uint32_t)(it / 3) * gstep));
+            }
+            if (g.width % EPV) {                   // the right edge cuts a vector: grey behind it
+                uint32_t keep[3][4];               // bits of the vector that are picture
+#pragma unroll
+                for (int ph = 0; ph < 3; ph++) {
+                    int nbits = (g.width - col3[ph]) * (8 * BPS);
+                    nbits = nbits < 0 ? 0 : (nbits > 128 ? 128 : nbits);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int b = nbits - 32 * k;
+                        keep[ph][k] = b >= 32 ? 0xffffffffu : (b <= 0 ? 0u : (1u << b) - 1u);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < PER_LANE; it++) {
+                    const uint32_t *m = keep[it % 3];
+                    v[it].x = (v[it].x & m[0]) | (grey & ~m[0]);
+                    v[it].y = (v[it].y & m[1]) | (grey & ~m[1]);
+                    v[it].z = (v[it].z & m[2]) | (grey & ~m[2]);
+                    v[it].w = (v[it].w & m[3]) | (grey & ~m[3]);
+                }
+            }
+        }
+        uint32_t seen = 0;                         // OR of every sample word: one depth test at the end
+#pragma unroll
+        for (int it = 0; it < PER_LANE; it++) {
+            const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
+            int4 *dst = reinterpret_cast<int4 *>(tile + doff3[it % 3] + (it / 3) * RSTEP3 * TPITCH);
+            if (BPS == 1) {
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul);
+                    o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul);
+                }
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+            } else {
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    seen |= w[k];
+                    o[k] = pk_level_shift(w[k], lsmul);
+                }
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (BPS == 2) bad = seen & ~(((1u << g.depth) - 1u) * 0x00010001u);
+        if (__any(bad != 0) && lane == 0)
+            atomicMin(&a.status[f], -34);            // FFV2AMD_ERR_RANGE
+    }
+    __syncthreads();
+    FFV2_PHASE_MARK(1);
+
+    // ---- phase B: horizontal lapping on the two vertical seams (rows in parallel) ----
+    // 96 rows x 2 seams = 192 filter instances = 3 rounds of 64 lanes.
+#pragma unroll 1
+    for (int round = 0; round < 3; round++) {
+        const int inst = round * 64 + lane;
+        const bool right = inst >= TILE;
+        const int r = right ? inst - TILE : inst;
+        const int y = y_org + r;
+        const bool act = (right ? seamR : seamL) & (y >= 0) & (y < grid_h);
+        if (__any(act)) {
+            int x[32];
+            const int4 *src = reinterpret_cast<const int4 *>(tile + r * TPITCH + (right ? 64 : 0));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int4 w = src[q];
+                x[8 * q + 0] = lo16(w.x); x[8 * q + 1] = hi16(w.x);
+                x[8 * q + 2] = lo16(w.y); x[8 * q + 3] = hi16(w.y);
+                x[8 * q + 4] = lo16(w.z); x[8 * q + 5] = hi16(w.z);
+                x[8 * q + 6] = lo16(w.w); x[8 * q + 7] = hi16(w.w);
+            }
+            lap32(x);
+            if (act) {
+                // keep the half that lies inside this block: left seam -> taps 16..31
+                // (tile cols 16..31), right seam -> taps 0..15 (tile cols 64..79)
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    o[k] = right ? pack16(x[2 * k], x[2 * k + 1]) : pack16(x[16 + 2 * k], x[17 + 2 * k]);
+                int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + (right ? 64 : 16));
+                dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+    __syncthreads();
+    FFV2_PHASE_MARK(2);
+
+    // ---- phase C: vertical lapping on the two horizontal seams, lane = column.  The lapped
+    // rows stay in registers: they are this column's inputs to phase D, which has the same
+    // lane = column orientation, so nothing goes back through LDS. ----
+    int x[64];
+    {
+        const int16_t *colp = tile + 16 + lane;
+        if (seamT) {                                         // wave-uniform
+            int t[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) t[k] = colp[k * TPITCH];
+            lap32(t);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = t[16 + k];                  // tile rows 16..31
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = colp[(16 + k) * TPITCH];
+        }
+        if (seamB) {
+            int t[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) t[k] = colp[(64 + k) * TPITCH];
+            lap32(t);
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[48 + k] = t[k];                  // tile rows 64..79
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[48 + k] = colp[(64 + k) * TPITCH];
+        }
+#pragma unroll
+        for (int k = 16; k < 48; k++) x[k] = colp[(16 + k) * TPITCH];      // rows 32..63: untouched by the seams
+    }
+    FFV2_PHASE_MARK(3);
+
+    tstage_back_half<WRITE_COEF>(x, lut, xb, a, f, bp, lane, lane_info);
     FFV2_PHASE_MARK(7);
     FFV2_PHASE_END;
 }

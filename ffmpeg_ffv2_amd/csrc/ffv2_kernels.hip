@@ -33,6 +33,11 @@
 
 #include "gen/fdct64_net.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#define FFV2_WALK_MIN 3      // block-planes per wavefront from which the column walk pays
+
 // OD_RSHIFT1(a) = (a + (a < 0)) >> 1 (ffv2.c:313).  Every value in the network is below
 // 2^23 in magnitude, so byte 3 of a is pure sign and
 // a - sext(a.byte3) = a + (a < 0) in one SDWA instruction instead of shift + add.
@@ -104,6 +109,12 @@ extern "C" void ffv2amd_debug_phase_raw(unsigned long long *out)       // [workg
 #endif
 
 namespace {
+
+// The T-stage workgroups are ONE wavefront: its DS instructions execute in issue order, so a
+// cross-lane hand-off through LDS needs no s_barrier and no counter drain -- only the compiler
+// must keep the LDS accesses in program order (per thread they may look independent).  Unlike
+// __syncthreads() this leaves global loads in flight (vmcnt untouched).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 
 constexpr int TILE      = 96;          // 64 + 2*16 halo
 constexpr int TPITCH    = 104;         // int16 per tile row: 208 B = 13 x 16 B (odd multiple -> b128 conflict free)
@@ -262,8 +273,8 @@ static_assert(64 * RPITCH * 4 <= LDS_BYTES, "raster buffer must fit in the tile"
 // gather, band energies, gains, record) and the coefficient stores.  Shared by the one-block
 // kernel and the column-walking kernel.  `xb` is the workgroup's LDS, free for reuse on entry
 // once the caller's barrier has passed.
-template <bool WRITE_COEF>
-__device__ __forceinline__ void tstage_back_half(int (&x)[64], const uint4 (&lut)[8], int *xb,
+template <bool WRITE_COEF, bool LOAD_LUT>
+__device__ __forceinline__ void tstage_back_half(int (&x)[64], uint4 (&lut)[8], int *xb,
                                                  const FFV2TStageArgs &a, const int f, const int bp,
                                                  const int lane, const int lane_info)
 {
@@ -275,24 +286,31 @@ __device__ __forceinline__ void tstage_back_half(int (&x)[64], const uint4 (&lut
         // __mul24 into a plain 32-bit multiply and then selects v_mul_lo_u32
         asm("" : "+v"(x[k]));
     }
-    __syncthreads();                                         // tile is dead: LDS becomes int32 [64][65]
+    wave_lds_fence();                                         // tile is dead: LDS becomes int32 [64][65]
 #define FFV2_MULRS FFV2_MULRS_NOOVF
     FDCT64_NET(x);
 #undef FFV2_MULRS
 #pragma unroll
     for (int v = 0; v < 64; v++) xb[lane * XPITCH + v] = x[OUTR[v]];      // tmp[64*col + v], ffv2.c:4957
-    __syncthreads();
+    if (LOAD_LUT) {
+        // the walking kernel fetches the scan table per block-plane, one transform ahead of its
+        // use (L1/L2 hits; held across the whole loop it would cost 32 registers)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            lut[i] = reinterpret_cast<const uint4 *>(a.lds_scan)[i * 64 + lane];
+    }
+    wave_lds_fence();
 
     // ---- phase E: row transforms (lane = vertical frequency v) ----
 #pragma unroll
     for (int k = 0; k < 64; k++) x[k] = xb[k * XPITCH + lane];            // tmp + v, stride 64, ffv2.c:4959
-    __syncthreads();
+    wave_lds_fence();
 #define FFV2_MULRS FFV2_MULRS_WRAP
     FDCT64_NET(x);
 #undef FFV2_MULRS
 #pragma unroll
     for (int u = 0; u < 64; u++) xb[lane * RPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
-    __syncthreads();
+    wave_lds_fence();
 
     // ---- phase F: scan-order gather, band energies, gains, coalesced 16-byte stores ----
     // lane owns coding indices q = 256*j + 4*lane + k (j < 16, k < 4) -> x[4j + k].
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
         if (__any(bad != 0) && lane == 0)
             atomicMin(&a.status[f], -34);            // FFV2AMD_ERR_RANGE
     }
-    __syncthreads();
+    wave_lds_fence();
     FFV2_PHASE_MARK(1);
 
     // ---- phase B: horizontal lapping on the two vertical seams (rows in parallel) ----
@@ -577,7 +595,7 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
             }
         }
     }
-    __syncthreads();
+    wave_lds_fence();
     FFV2_PHASE_MARK(2);
 
     // ---- phase C: vertical lapping on the two horizontal seams, lane = column.  The lapped
@@ -613,9 +631,358 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_kernel(const FFV2TStageArgs
     }
     FFV2_PHASE_MARK(3);
 
-    tstage_back_half<WRITE_COEF>(x, lut, xb, a, f, bp, lane, lane_info);
+    tstage_back_half<WRITE_COEF, false>(x, lut, xb, a, f, bp, lane, lane_info);
     FFV2_PHASE_MARK(7);
     FFV2_PHASE_END;
+}
+
+// ---------------------------------------------------------------------------
+// T-stage, column-walking variant
+// ---------------------------------------------------------------------------
+// The one-block kernel above filters every seam from both sides: per block-plane 3 rounds of
+// horizontal lapping (96 halo rows x 2 seams) and 2 of vertical lapping, against the 2 rounds a
+// block strictly owns.  Here ONE wavefront walks a run of block-planes DOWN a column of
+// superblocks (same frame, plane and sbx; sby ascending):
+//   * each step loads only the 64 new picture rows [64j+16, 64j+80) x 96 columns (the rows above
+//     came with the previous step), laps them horizontally (64 rows x 2 seams = 2 rounds) and
+//     filters the ONE horizontal seam below the block (1 round);
+//   * the lower half of that seam's output (16 rows, lane = column) stays in registers as the
+//     first 16 input rows of the next block -- the seam is never filtered twice;
+//   * 3 lapping rounds per block-plane instead of 5, a third fewer tile loads, and the next
+//     step's loads are issued before this step's transforms and coefficient stores (vmcnt is
+//     in-order: a load issued behind the stores would wait for them).
+// A run starts (and restarts at the top of the next column) with a pre-step that loads and
+// laps the 32 rows around the seam above the first block.  The block-planes of a launch are
+// dealt in equal runs to exactly as many wavefronts as the chip holds at once
+// (ffv2_launch_tstage), so there is no dispatch tail.
+constexpr int WLDS_BYTES = 64 * RPITCH * 4;        // raster buffer is the largest tenant (17 664 B)
+static_assert(64 * TPITCH * 2 <= WLDS_BYTES && 64 * XPITCH * 4 <= WLDS_BYTES, "walk kernel LDS");
+
+template <int BPS> struct WalkGeom {
+    static constexpr int EPV = 16 / BPS;           // samples per 16-byte vector
+    static constexpr int VPR = TILE / EPV;         // vectors per 96-sample tile row (6 | 12)
+    static constexpr int RSTEP = 64 / VPR, CSTEP = 64 % VPR;
+    static constexpr int RSTEP3 = 3 * 64 / VPR;    // rows per three iterations
+    static_assert((3 * CSTEP) % VPR == 0, "three-phase addressing");
+};
+
+// A tile request: NROWS x 96 samples at picture position (x_org, y0), vector index it*64 + lane,
+// row-major.  walk_issue sends out the 16-byte loads and returns at once; walk_fix, called when
+// the data is needed, turns everything outside the picture into mid-grey (= 0 after the level
+// shift, ffv2enc.c:69-71).  No load is predicated -- a vector outside the picture reads the
+// plane's first 16 bytes instead and is replaced afterwards -- so that the compiler never has
+// to wait between loads.  r3/c3: the lane's three (row, first column) address phases.
+struct WalkReq {
+    uint32_t okmask;        // bit `it`: vector `it` of this lane lies (at least partly) inside the picture
+    bool inside;            // wave-uniform: the whole tile does
+};
+
+template <int BPS, int NROWS>
+__device__ __forceinline__ WalkReq walk_issue(uint4 (&v)[NROWS * WalkGeom<BPS>::VPR / 64], const uint8_t *plane,
+                                              const FFV2Geom &g, const int x_org, const int y0,
+                                              const int (&r3)[3], const int (&c3)[3])
+{
+    using G = WalkGeom<BPS>;
+    constexpr int PER_LANE = NROWS * G::VPR / 64;
+    static_assert(PER_LANE % 3 == 0, "whole address periods");
+    uint32_t goff[3];
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++)
+        goff[ph] = (uint32_t)(y0 + r3[ph]) * (uint32_t)g.row_pitch + (uint32_t)(x_org + c3[ph]) * BPS;
+    const uint32_t gstep = G::RSTEP3 * (uint32_t)g.row_pitch;
+    WalkReq q;
+    q.inside = (x_org >= 0) & (x_org + TILE <= g.width) & (y0 >= 0) & (y0 + NROWS <= g.height);
+    q.okmask = 0xffffffffu;
+    uint32_t off[PER_LANE];                        // 32-bit offsets from the (uniform) plane base
+#pragma unroll
+    for (int it = 0; it < PER_LANE; it++) off[it] = goff[it % 3] + (uint32_t)(it / 3) * gstep;
+    if (!q.inside) {
+        bool cok[3];
+#pragma unroll
+        for (int ph = 0; ph < 3; ph++) cok[ph] = (uint32_t)(x_org + c3[ph]) < (uint32_t)g.width;
+        uint32_t m = 0;
+#pragma unroll
+        for (int it = 0; it < PER_LANE; it++) {
+            const bool ok = cok[it % 3] & ((uint32_t)(y0 + r3[it % 3] + (it / 3) * G::RSTEP3) < (uint32_t)g.height);
+            off[it] = ok ? off[it] : 0u;
+            m |= (ok ? 1u : 0u) << it;
+        }
+        q.okmask = m;
+    }
+#pragma unroll
+    for (int it = 0; it < PER_LANE; it++)
+        v[it] = *reinterpret_cast<const uint4 *>(plane + off[it]);
+    return q;
+}
+
+template <int BPS, int NROWS>
+__device__ __forceinline__ void walk_fix(uint4 (&v)[NROWS * WalkGeom<BPS>::VPR / 64], const WalkReq q,
+                                         const FFV2Geom &g, const int x_org, const int sh, const int (&c3)[3])
+{
+    using G = WalkGeom<BPS>;
+    constexpr int PER_LANE = NROWS * G::VPR / 64;
+    if (q.inside) return;
+    const uint32_t grey = BPS == 1 ? 0x80808080u : (2048u >> sh) * 0x00010001u;
+#pragma unroll
+    for (int it = 0; it < PER_LANE; it++) {
+        const bool ok = (q.okmask >> it) & 1u;
+        v[it].x = ok ? v[it].x : grey; v[it].y = ok ? v[it].y : grey;
+        v[it].z = ok ? v[it].z : grey; v[it].w = ok ? v[it].w : grey;
+    }
+    if (g.width % G::EPV) {                        // the right edge cuts a vector: grey behind it
+#pragma unroll
+        for (int ph = 0; ph < 3; ph++) {
+            int nbits = (g.width - (x_org + c3[ph])) * (8 * BPS);
+            nbits = nbits < 0 ? 0 : (nbits > 128 ? 128 : nbits);
+            uint32_t keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int b = nbits - 32 * k;
+                keep[k] = b >= 32 ? 0xffffffffu : (b <= 0 ? 0u : (1u << b) - 1u);
+            }
+#pragma unroll
+            for (int it = ph; it < PER_LANE; it += 3) {
+                v[it].x = (v[it].x & keep[0]) | (grey & ~keep[0]);
+                v[it].y = (v[it].y & keep[1]) | (grey & ~keep[1]);
+                v[it].z = (v[it].z & keep[2]) | (grey & ~keep[2]);
+                v[it].w = (v[it].w & keep[3]) | (grey & ~keep[3]);
+            }
+        }
+    }
+}
+
+// level shift + int16 store of a loaded tile; returns the OR of all 16-bit sample words
+template <int BPS, int NROWS>
+__device__ __forceinline__ uint32_t walk_store(const uint4 (&v)[NROWS * WalkGeom<BPS>::VPR / 64], int16_t *tile,
+                                               const int sh, const int (&r3)[3], const int (&c3)[3])
+{
+    using G = WalkGeom<BPS>;
+    constexpr int PER_LANE = NROWS * G::VPR / 64;
+    const uint32_t lsmul = (1u << sh) * 0x00010001u;
+    uint32_t seen = 0;
+#pragma unroll
+    for (int it = 0; it < PER_LANE; it++) {
+        const uint32_t w[4] = { v[it].x, v[it].y, v[it].z, v[it].w };
+        int4 *dst = reinterpret_cast<int4 *>(tile + (r3[it % 3] + (it / 3) * G::RSTEP3) * TPITCH + c3[it % 3]);
+        if (BPS == 1) {
+            uint32_t o[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                o[2 * k]     = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c010c00u), lsmul);
+                o[2 * k + 1] = pk_level_shift(__builtin_amdgcn_perm(0, w[k], 0x0c030c02u), lsmul);
+            }
+            dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+            dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+        } else {
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                seen |= w[k];
+                o[k] = pk_level_shift(w[k], lsmul);
+            }
+            dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    return seen;
+}
+
+// one horizontal filter instance: tile row r, left (tile columns 0..31, keeps 16..31) or
+// right seam (columns 64..95, keeps 64..79)
+__device__ __forceinline__ void walk_hlap(int16_t *tile, const int r, const bool right, const bool act)
+{
+    int x[32];
+    const int4 *src = reinterpret_cast<const int4 *>(tile + r * TPITCH + (right ? 64 : 0));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int4 w = src[q];
+        x[8 * q + 0] = lo16(w.x); x[8 * q + 1] = hi16(w.x);
+        x[8 * q + 2] = lo16(w.y); x[8 * q + 3] = hi16(w.y);
+        x[8 * q + 4] = lo16(w.z); x[8 * q + 5] = hi16(w.z);
+        x[8 * q + 6] = lo16(w.w); x[8 * q + 7] = hi16(w.w);
+    }
+    lap32(x);
+    if (act) {
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            o[k] = right ? pack16(x[2 * k], x[2 * k + 1]) : pack16(x[16 + 2 * k], x[17 + 2 * k]);
+        int4 *dst = reinterpret_cast<int4 *>(tile + r * TPITCH + (right ? 64 : 16));
+        dst[0] = make_int4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_int4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// Runs of block-planes handed to the workgroups of one launch: tier t holds cnt[t] runs of
+// len[t] block-planes starting at block-plane base[t]; workgroups take runs in id order.  Long
+// runs first (few pre-steps), ever shorter ones behind them, so that the wavefront slots of the
+// chip -- refilled by the dispatcher as workgroups retire -- all drain at about the same time.
+struct WalkTiers {
+    uint32_t cnt[4], len[4], base[4];
+};
+
+template <int BPS, bool WRITE_COEF>
+__global__ __launch_bounds__(64, 2) void ffv2_tstage_walk_kernel(const FFV2TStageArgs a, const uint32_t total,
+                                                                 const WalkTiers tiers)
+{
+    using G = WalkGeom<BPS>;
+    constexpr int PL_MAIN = 64 * G::VPR / 64, PL_PRE = 32 * G::VPR / 64;
+    __shared__ int4 lds_raw[WLDS_BYTES / 16];
+    int16_t  *tile = reinterpret_cast<int16_t *>(lds_raw);
+    int      *xb   = reinterpret_cast<int *>(lds_raw);
+
+    const FFV2Geom &g = a.g;
+    const int lane = threadIdx.x;
+
+    uint32_t n, n_end;
+    {
+        uint32_t b = blockIdx.x, t = 0;
+        while (t < 3 && b >= tiers.cnt[t]) { b -= tiers.cnt[t]; t++; }
+        // workgroups b, b+8, ... share an XCD: give each XCD one contiguous stretch of a tier's runs
+        if ((tiers.cnt[t] & 7u) == 0 && b < tiers.cnt[t]) b = (b & 7u) * (tiers.cnt[t] >> 3) + (b >> 3);
+        n = tiers.base[t] + b * tiers.len[t];
+        n_end = n + tiers.len[t] < total ? n + tiers.len[t] : total;
+        if (b >= tiers.cnt[t] || n >= n_end) return;
+    }
+
+    const int lane_info = LANE_BAND[lane];
+    const int sh = 12 - g.depth;
+#ifdef FFV2_PHASE_TIMING
+    // slots: 0 start (100 MHz), 1 HW_ID, 2 life (100 MHz), 3 front-half ticks, 4 back-half ticks,
+    // 5 pre-step ticks, 6 block-planes done
+    const unsigned long long wrt0_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_ = __builtin_amdgcn_s_memtime(), wacc_[3] = {};
+    unsigned wdone_ = 0;
+#define WALK_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); wacc_[i] += t_ - wt_; wt_ = t_; } while (0)
+#else
+#define WALK_MARK(i)
+#endif
+
+    // the lane's three (row, column) address phases of a tile load, see walk_load
+    int r3[3], c3[3];
+    {
+        int r = lane / G::VPR, cv = lane - (lane / G::VPR) * G::VPR;
+#pragma unroll
+        for (int ph = 0; ph < 3; ph++) {
+            r3[ph] = r; c3[ph] = cv * G::EPV;
+            r += G::RSTEP; cv += G::CSTEP;
+            if (cv >= G::VPR) { cv -= G::VPR; r++; }
+        }
+    }
+
+    // block-planes are numbered column by column: n = (((f*planes + p)*nsx + sbx)*nsy + sby
+    uint32_t col = n / (uint32_t)g.nsy;
+    int j = (int)(n - col * (uint32_t)g.nsy);
+    bool fresh = true;                             // a pre-step is due (start of the run / top of a column)
+    int f = 0, p = 0, sbx = 0, x_org = 0;
+    bool seamL = false, seamR = false;
+    const uint8_t *plane = nullptr;
+    uint4 v[PL_MAIN];                              // the step's 64 new rows, requested one step ahead
+    WalkReq vq{0xffffffffu, true};
+    int carry[16];                                 // rows 0..15 of the current block, lane = column
+    const uint32_t himask = ~(((1u << g.depth) - 1u) * 0x00010001u);
+
+#pragma unroll 1
+    for (; n < n_end; n++) {
+        uint32_t seen = 0;
+        if (fresh) {
+            const uint32_t fp = col / (uint32_t)g.nsx;
+            sbx = (int)(col - fp * (uint32_t)g.nsx);
+            f = (int)(fp / (uint32_t)g.planes);
+            p = (int)(fp - (uint32_t)f * (uint32_t)g.planes);
+            plane = a.frames + (size_t)f * g.frame_stride + (size_t)p * g.plane_stride;
+            x_org = sbx * 64 - 16;
+            seamL = sbx > 0; seamR = sbx + 1 < g.nsx;
+            // pre-step: the 32 rows around the seam above block j (all grey above the picture)
+            uint4 pv[PL_PRE];
+            const WalkReq pq = walk_issue<BPS, 32>(pv, plane, g, x_org, j * 64 - 16, r3, c3);
+            vq = walk_issue<BPS, 64>(v, plane, g, x_org, j * 64 + 16, r3, c3);
+            walk_fix<BPS, 32>(pv, pq, g, x_org, sh, c3);
+            seen |= walk_store<BPS, 32>(pv, tile, sh, r3, c3);
+            wave_lds_fence();
+            {
+                const bool right = lane >= 32;
+                const bool act = right ? seamR : seamL;
+                if (__any(act)) walk_hlap(tile, lane & 31, right, act);
+            }
+            wave_lds_fence();
+            const int16_t *colp = tile + 16 + lane;
+            if (j > 0) {
+                int t[32];
+#pragma unroll
+                for (int k = 0; k < 32; k++) t[k] = colp[k * TPITCH];
+                lap32(t);
+#pragma unroll
+                for (int k = 0; k < 16; k++) carry[k] = t[16 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) carry[k] = colp[(16 + k) * TPITCH];
+            }
+            wave_lds_fence();
+            fresh = false;
+            // the first block's rows have landed by now; say so here, so that the loop's common
+            // path below carries no pending load (else every step would wait, through the in-order
+            // vmcnt, for the previous step's coefficient stores)
+#pragma unroll
+            for (int it = 0; it < PL_MAIN; it++) asm volatile("" :: "v"(v[it].x), "v"(v[it].y), "v"(v[it].z), "v"(v[it].w));
+            WALK_MARK(2);
+        }
+        // ---- the 64 new rows: picture rows [64j+16, 64j+80) = tile rows 0..63 ----
+        walk_fix<BPS, 64>(v, vq, g, x_org, sh, c3);
+        seen |= walk_store<BPS, 64>(v, tile, sh, r3, c3);
+        if (BPS == 2 && __any((seen & himask) != 0) && lane == 0)
+            atomicMin(&a.status[f], -34);            // FFV2AMD_ERR_RANGE
+        wave_lds_fence();
+        if (seamL) walk_hlap(tile, lane, false, true);
+        if (seamR) walk_hlap(tile, lane, true, true);
+        wave_lds_fence();
+        int x[64];
+        {
+            const int16_t *colp = tile + 16 + lane;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = carry[k];
+#pragma unroll
+            for (int k = 0; k < 32; k++) x[16 + k] = colp[k * TPITCH];
+            if (j + 1 < g.nsy) {                             // the seam below: filtered once, shared
+                int t[32];
+#pragma unroll
+                for (int k = 0; k < 32; k++) t[k] = colp[(32 + k) * TPITCH];
+                lap32(t);
+#pragma unroll
+                for (int k = 0; k < 16; k++) { x[48 + k] = t[k]; carry[k] = t[16 + k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[48 + k] = colp[(32 + k) * TPITCH];
+            }
+        }
+        const int bp = (j * g.nsx + sbx) * g.planes + p;
+        // next step's rows: requested now, ahead of the transforms and the coefficient stores
+        j++;
+        if (j == g.nsy) { j = 0; col++; fresh = true; }
+        if (!fresh && n + 1 < n_end) {
+            vq = walk_issue<BPS, 64>(v, plane, g, x_org, j * 64 + 16, r3, c3);
+        } else {
+            // nothing carried into the next step: end the old tile's live range here, so that the
+            // loads above can land in the very registers the loop carries (no wait-and-copy)
+#pragma unroll
+            for (int it = 0; it < PL_MAIN; it++)     // "defined" without an instruction
+                asm("" : "=v"(v[it].x), "=v"(v[it].y), "=v"(v[it].z), "=v"(v[it].w));
+        }
+        uint4 lut[8];
+        WALK_MARK(0);
+        tstage_back_half<WRITE_COEF, true>(x, lut, xb, a, f, bp, lane, lane_info);
+        WALK_MARK(1);
+#ifdef FFV2_PHASE_TIMING
+        wdone_++;
+#endif
+    }
+#ifdef FFV2_PHASE_TIMING
+    if (lane == 0) {
+        unsigned long long *pt_ = g_phase_buf + (size_t)blockIdx.x * 8;
+        pt_[0] = wrt0_; pt_[1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+        pt_[2] = __builtin_amdgcn_s_memrealtime() - wrt0_;
+        pt_[3] = wacc_[0]; pt_[4] = wacc_[1]; pt_[5] = wacc_[2]; pt_[6] = wdone_;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -808,11 +1175,70 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
 
 }  // namespace
 
+// Wavefronts the chip holds at once for the walking kernel (occupancy x CUs), per device.
+static int walk_slots(bool bps2, bool wc)
+{
+    static int cache[16][4];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    int &c = cache[dev][(bps2 ? 2 : 0) + (wc ? 1 : 0)];
+    if (c == 0) {
+        int per_cu = 0, cus = 0;
+        const void *fn = bps2 ? (wc ? (const void *)ffv2_tstage_walk_kernel<2, true> : (const void *)ffv2_tstage_walk_kernel<2, false>)
+                              : (wc ? (const void *)ffv2_tstage_walk_kernel<1, true> : (const void *)ffv2_tstage_walk_kernel<1, false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || per_cu < 1 || cus < 1)
+            c = -1;
+        else
+            c = per_cu * cus;
+    }
+    return c;
+}
+
 hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
 {
-    const dim3 grid((unsigned)((a.g.nblk + 7) / 8 * 8), (unsigned)a.nframes), block(64);
     const bool wc = a.coef != nullptr;
-    if (a.g.bytes_per_sample == 1) {
+    const bool bps2 = a.g.bytes_per_sample != 1;
+    // Column-walking kernel when every wavefront slot gets a run of at least FFV2_WALK_MIN
+    // block-planes; the one-block kernel otherwise (small pictures, single frames).
+    static const int walk_mode = getenv("FFV2AMD_TSTAGE") ? atoi(getenv("FFV2AMD_TSTAGE")) : -1;   // 0 block, 1 walk, -1 auto
+    const uint64_t total64 = (uint64_t)a.g.nblk * (uint64_t)a.nframes;
+    const int slots = walk_mode == 0 ? 0 : walk_slots(bps2, wc);
+    if (slots > 0 && total64 < (1ull << 31) && (walk_mode == 1 || total64 >= (uint64_t)slots * FFV2_WALK_MIN)) {
+        const uint32_t total = (uint32_t)total64;
+        // Tiers (measured on C3, tools/sweep_tiers.sh): `slots` runs each of L = 2/3 of an even
+        // share, of L/3 and of L/6 block-planes, the rest as single block-planes: 16, 5, 2, 1 for
+        // eight 4K frames.  FFV2AMD_WALK_TIERS="a,b,c,d" overrides the four lengths (experiments).
+        static const char *tier_env = getenv("FFV2AMD_WALK_TIERS");
+        uint32_t len[4];
+        len[0] = (uint32_t)(total * 0.67 / slots); if (len[0] < 1) len[0] = 1;
+        len[1] = len[0] / 3 ? len[0] / 3 : 1; len[2] = len[1] / 2 ? len[1] / 2 : 1; len[3] = 1;
+        if (tier_env) {
+            unsigned t0, t1, t2, t3;
+            if (sscanf(tier_env, "%u,%u,%u,%u", &t0, &t1, &t2, &t3) == 4 && t0 && t1 && t2 && t3) { len[0] = t0; len[1] = t1; len[2] = t2; len[3] = t3; }
+        }
+        WalkTiers tiers{};
+        uint32_t at = 0, groups = 0;
+        for (int t = 0; t < 4; t++) {
+            const uint32_t left = total - at;
+            uint32_t cnt = t < 3 ? (uint32_t)slots : (left + len[t] - 1) / len[t];
+            if ((uint64_t)cnt * len[t] > left) cnt = (left + len[t] - 1) / len[t];
+            tiers.cnt[t] = cnt; tiers.len[t] = len[t]; tiers.base[t] = at;
+            at += cnt * len[t] < left ? cnt * len[t] : left;
+            groups += cnt;
+        }
+        const dim3 grid(groups), block(64);
+        if (bps2) {
+            if (wc) hipLaunchKernelGGL((ffv2_tstage_walk_kernel<2, true>),  grid, block, 0, s, a, total, tiers);
+            else    hipLaunchKernelGGL((ffv2_tstage_walk_kernel<2, false>), grid, block, 0, s, a, total, tiers);
+        } else {
+            if (wc) hipLaunchKernelGGL((ffv2_tstage_walk_kernel<1, true>),  grid, block, 0, s, a, total, tiers);
+            else    hipLaunchKernelGGL((ffv2_tstage_walk_kernel<1, false>), grid, block, 0, s, a, total, tiers);
+        }
+        return hipGetLastError();
+    }
+    const dim3 grid((unsigned)((a.g.nblk + 7) / 8 * 8), (unsigned)a.nframes), block(64);
+    if (!bps2) {
         if (wc) hipLaunchKernelGGL((ffv2_tstage_kernel<1, true>),  grid, block, 0, s, a);
         else    hipLaunchKernelGGL((ffv2_tstage_kernel<1, false>), grid, block, 0, s, a);
     } else {

@@ -1,0 +1,11 @@
+set -o pipefail
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$1; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --steps 60 --warmup 10"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sq" -o p -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_sq.err" || exit 1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_lds" -o p -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_lds.err" || exit 1
+cd "$REPO" && python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
+find "$OUT" -name "*.csv" -size +8M -delete

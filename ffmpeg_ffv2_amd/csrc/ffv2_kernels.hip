@@ -36,7 +36,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#define FFV2_WALK_MIN 3      // block-planes per wavefront from which the column walk pays
+#define FFV2_WALK_MIN 2      // block-planes per wavefront from which the column walk pays
 
 // OD_RSHIFT1(a) = (a + (a < 0)) >> 1 (ffv2.c:313).  Every value in the network is below
 // 2^23 in magnitude, so byte 3 of a is pure sign and
@@ -812,12 +812,18 @@ __device__ __forceinline__ void walk_hlap(int16_t *tile, const int r, const bool
     }
 }
 
-// Runs of block-planes handed to the workgroups of one launch: tier t holds cnt[t] runs of
-// len[t] block-planes starting at block-plane base[t]; workgroups take runs in id order.  Long
+// Runs handed to the workgroups of one launch.  Every column of superblocks (frame, plane, sbx)
+// is cut into the same segments of decreasing length len[t] starting at superblock row joff[t];
+// tier t = segment t of every column, and workgroups take runs tier by tier in id order: long
 // runs first (few pre-steps), ever shorter ones behind them, so that the wavefront slots of the
-// chip -- refilled by the dispatcher as workgroups retire -- all drain at about the same time.
+// chip -- refilled by the dispatcher as workgroups retire -- drain at about the same time.
+// Inside a tier consecutive runs are horizontally adjacent columns, and the workgroups of one
+// XCD (b, b+8, ...) get a contiguous stretch of them: neighbours that share a 32-sample halo
+// walk down side by side through the same L2 and the same DRAM pages.
+#define FFV2_WALK_MAX_TIERS 24
 struct WalkTiers {
-    uint32_t cnt[4], len[4], base[4];
+    uint32_t ntiers, ncols, ncols8;                 // ncols8 = ncols rounded up to a multiple of 8
+    uint16_t len[FFV2_WALK_MAX_TIERS], joff[FFV2_WALK_MAX_TIERS];
 };
 
 template <int BPS, bool WRITE_COEF>
@@ -836,12 +842,11 @@ __global__ __launch_bounds__(64, 2) void ffv2_tstage_walk_kernel(const FFV2TStag
     uint32_t n, n_end;
     {
         uint32_t b = blockIdx.x, t = 0;
-        while (t < 3 && b >= tiers.cnt[t]) { b -= tiers.cnt[t]; t++; }
-        // workgroups b, b+8, ... share an XCD: give each XCD one contiguous stretch of a tier's runs
-        if ((tiers.cnt[t] & 7u) == 0 && b < tiers.cnt[t]) b = (b & 7u) * (tiers.cnt[t] >> 3) + (b >> 3);
-        n = tiers.base[t] + b * tiers.len[t];
-        n_end = n + tiers.len[t] < total ? n + tiers.len[t] : total;
-        if (b >= tiers.cnt[t] || n >= n_end) return;
+        while (b >= tiers.ncols8) { b -= tiers.ncols8; t++; }
+        const uint32_t c = (b & 7u) * (tiers.ncols8 >> 3) + (b >> 3);
+        if (c >= tiers.ncols || t >= tiers.ntiers) return;
+        n = c * (uint32_t)g.nsy + tiers.joff[t];
+        n_end = n + tiers.len[t];
     }
 
     const int lane_info = LANE_BAND[lane];
@@ -1206,28 +1211,28 @@ hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
     const int slots = walk_mode == 0 ? 0 : walk_slots(bps2, wc);
     if (slots > 0 && total64 < (1ull << 31) && (walk_mode == 1 || total64 >= (uint64_t)slots * FFV2_WALK_MIN)) {
         const uint32_t total = (uint32_t)total64;
-        // Tiers (measured on C3, tools/sweep_tiers.sh): `slots` runs each of L = 2/3 of an even
-        // share, of L/3 and of L/6 block-planes, the rest as single block-planes: 16, 5, 2, 1 for
-        // eight 4K frames.  FFV2AMD_WALK_TIERS="a,b,c,d" overrides the four lengths (experiments).
-        static const char *tier_env = getenv("FFV2AMD_WALK_TIERS");
-        uint32_t len[4];
-        len[0] = (uint32_t)(total * 0.67 / slots); if (len[0] < 1) len[0] = 1;
-        len[1] = len[0] / 3 ? len[0] / 3 : 1; len[2] = len[1] / 2 ? len[1] / 2 : 1; len[3] = 1;
-        if (tier_env) {
-            unsigned t0, t1, t2, t3;
-            if (sscanf(tier_env, "%u,%u,%u,%u", &t0, &t1, &t2, &t3) == 4 && t0 && t1 && t2 && t3) { len[0] = t0; len[1] = t1; len[2] = t2; len[3] = t3; }
-        }
+        // Segment lengths: each takes FFV2AMD_WALK_SEG (default 0.55) of what is left of the column,
+        // at least one superblock: 17, 9, 4, 2, 1, 1 for the 34 rows of eight 4K pictures.
+        static const double seg_frac = getenv("FFV2AMD_WALK_SEG") ? atof(getenv("FFV2AMD_WALK_SEG")) : 0.55;
+        static const double seg_cap = getenv("FFV2AMD_WALK_CAP") ? atof(getenv("FFV2AMD_WALK_CAP")) : 0.7;
+        // ... but no run longer than seg_cap of a slot's even share, so that small launches
+        // (fewer columns than slots) still spread over the whole chip
+        int cap = (int)(seg_cap * (double)total / slots + 0.5);
+        if (cap < 1) cap = 1;
         WalkTiers tiers{};
-        uint32_t at = 0, groups = 0;
-        for (int t = 0; t < 4; t++) {
-            const uint32_t left = total - at;
-            uint32_t cnt = t < 3 ? (uint32_t)slots : (left + len[t] - 1) / len[t];
-            if ((uint64_t)cnt * len[t] > left) cnt = (left + len[t] - 1) / len[t];
-            tiers.cnt[t] = cnt; tiers.len[t] = len[t]; tiers.base[t] = at;
-            at += cnt * len[t] < left ? cnt * len[t] : left;
-            groups += cnt;
+        tiers.ncols = (uint32_t)(a.g.nsx * a.g.planes * a.nframes);
+        tiers.ncols8 = (tiers.ncols + 7u) / 8u * 8u;
+        int left = a.g.nsy, at = 0;
+        while (left > 0) {
+            int l = (int)(left * seg_frac + 0.5);
+            if (l > cap) l = cap;
+            if (l < 1) l = 1;
+            if (tiers.ntiers == FFV2_WALK_MAX_TIERS - 1) l = left;
+            tiers.len[tiers.ntiers] = (uint16_t)l; tiers.joff[tiers.ntiers] = (uint16_t)at;
+            tiers.ntiers++; at += l; left -= l;
         }
-        const dim3 grid(groups), block(64);
+        const uint32_t groups = tiers.ntiers * tiers.ncols8;
+                const dim3 grid(groups), block(64);
         if (bps2) {
             if (wc) hipLaunchKernelGGL((ffv2_tstage_walk_kernel<2, true>),  grid, block, 0, s, a, total, tiers);
             else    hipLaunchKernelGGL((ffv2_tstage_walk_kernel<2, false>), grid, block, 0, s, a, total, tiers);

@@ -194,7 +194,7 @@ def main():
                        "pipelined_estage": args.pipeline,
                        "parallelism": "frame-parallel x%d, no data-path collective" % world,
                        "packet_bytes_frame0": len(packets[0])},
-            "roofline": {"bound": "hbm", "kernel": "ffv2_tstage_kernel",
+            "roofline": {"bound": "hbm", "kernel": enc.tstage_kernel_name(F),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,

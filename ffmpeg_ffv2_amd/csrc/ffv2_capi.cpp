@@ -570,6 +570,13 @@ int ffv2amd_encoder_flush(ffv2amd_encoder *e, void *stream)
     return FFV2AMD_OK;
 }
 
+const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *e, int nframes)
+{
+    if (!e || nframes < 1) return "";
+    if (hipSetDevice(e->device) != hipSuccess) return "";
+    return ffv2_tstage_kernel_name(e->geom, nframes, e->coef_sink != nullptr);
+}
+
 int ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *e, int32_t *d_coef)
 {
     if (!e) return FFV2AMD_ERR_INVAL;

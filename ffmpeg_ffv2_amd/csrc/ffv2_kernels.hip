@@ -1200,16 +1200,29 @@ static int walk_slots(bool bps2, bool wc)
     return c;
 }
 
+// Column-walking kernel when every wavefront slot gets at least FFV2_WALK_MIN block-planes;
+// the one-block kernel otherwise (small pictures).  Returns the slot count, 0 = one-block kernel.
+static int tstage_walk_slots(const FFV2Geom &g, int nframes, bool wc)
+{
+    static const int walk_mode = getenv("FFV2AMD_TSTAGE") ? atoi(getenv("FFV2AMD_TSTAGE")) : -1;   // 0 block, 1 walk, -1 auto
+    const uint64_t total64 = (uint64_t)g.nblk * (uint64_t)nframes;
+    const int slots = walk_mode == 0 ? 0 : walk_slots(g.bytes_per_sample != 1, wc);
+    if (slots > 0 && total64 < (1ull << 31) && (walk_mode == 1 || total64 >= (uint64_t)slots * FFV2_WALK_MIN)) return slots;
+    return 0;
+}
+
+const char *ffv2_tstage_kernel_name(const FFV2Geom &g, int nframes, bool wc)
+{
+    return tstage_walk_slots(g, nframes, wc) > 0 ? "ffv2_tstage_walk_kernel" : "ffv2_tstage_kernel";
+}
+
 hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s)
 {
     const bool wc = a.coef != nullptr;
     const bool bps2 = a.g.bytes_per_sample != 1;
-    // Column-walking kernel when every wavefront slot gets a run of at least FFV2_WALK_MIN
-    // block-planes; the one-block kernel otherwise (small pictures, single frames).
-    static const int walk_mode = getenv("FFV2AMD_TSTAGE") ? atoi(getenv("FFV2AMD_TSTAGE")) : -1;   // 0 block, 1 walk, -1 auto
     const uint64_t total64 = (uint64_t)a.g.nblk * (uint64_t)a.nframes;
-    const int slots = walk_mode == 0 ? 0 : walk_slots(bps2, wc);
-    if (slots > 0 && total64 < (1ull << 31) && (walk_mode == 1 || total64 >= (uint64_t)slots * FFV2_WALK_MIN)) {
+    const int slots = tstage_walk_slots(a.g, a.nframes, wc);
+    if (slots > 0) {
         const uint32_t total = (uint32_t)total64;
         // Segment lengths: each takes FFV2AMD_WALK_SEG (default 0.55) of what is left of the column,
         // at least one superblock: 17, 9, 4, 2, 1, 1 for the 34 rows of eight 4K pictures.

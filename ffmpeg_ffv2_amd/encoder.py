@@ -200,6 +200,9 @@ class FFV2Encoder:
     def profile(self, on=True):
         _lib.check(self._lib.ffv2amd_profile_enable(self._h, 1 if on else 0), "profile_enable")
 
+    def tstage_kernel_name(self, nframes):
+        return self._lib.ffv2amd_tstage_kernel_name(self._h, int(nframes)).decode()
+
     def profile_read(self):
         """-> (tstage_ms_total, estage_ms_total, launches) since the last read."""
         t, x, n = C.c_double(0), C.c_double(0), C.c_int(0)

@@ -147,6 +147,9 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
  * profile_read waits for the recorded events, returns the summed durations (ms)
  * and the number of batch launches since the last read, and resets the counters. */
 int  ffv2amd_profile_enable(ffv2amd_encoder *enc, int on);
+/* Name of the T-stage kernel a *_batch_device call of `nframes` frames launches (two variants:
+ * one 64x64 block-plane per wavefront, or wavefronts walking down columns of superblocks). */
+const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *enc, int nframes);
 int  ffv2amd_profile_read(ffv2amd_encoder *enc, double *tstage_ms, double *estage_ms, int *launches);
 
 /* Host helpers with no GPU work (unit-tested on CPU):

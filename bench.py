@@ -39,6 +39,56 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 PREROLL_GROUP, PREROLL_MAX = 10, 150
 
 
+def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pinned, barrier):
+    """Host frames in, host packets out through the asynchronous ring (ffv2amd_ring_*): the
+    metric as SURVEY.md 8(d) words it, PCIe included.  Returns (seconds, packets, bytes per frame)."""
+    enc = FFV2Encoder(W, H, fmt, device=local, max_batch=1)
+    enc.ring_open(depth)
+    nsrc = host_frames.shape[0]
+    if pinned:
+        src = enc.pinned_frames(nsrc)
+        src[:] = host_frames
+    else:
+        src = host_frames
+    frame_bytes = enc.info.planes * enc.info.width * enc.info.height * enc.dtype.itemsize
+
+    def run(n):
+        packets, sent = [], 0
+        while len(packets) < n:
+            while sent < n and enc.ring_send(src[sent % nsrc], tag=sent, pinned=pinned):
+                sent += 1
+            tag, pk = enc.ring_receive(wait=True)
+            assert tag == len(packets), "ring delivered out of order"
+            packets.append(pk)
+        return packets
+
+    run(min(nframes, 2 * depth))                    # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    packets = run(nframes)
+    barrier()
+    dt = time.perf_counter() - t0
+    enc.ring_close()
+    enc.free_pinned()
+    enc.close()
+    return dt, packets, frame_bytes
+
+
+def h2d_rate(dev, nbytes, reps=8):
+    """Plain pinned-host -> device copy rate (GB/s) of frame-sized buffers: what PCIe gives."""
+    src = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +103,9 @@ def main():
                          "(measured: ~1 % more Mpix/s, but the T-stage timing then includes the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed clock-settling pre-roll")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-frames-in / host-packets-out phase")
+    ap.add_argument("--host-frames", type=int, default=48, help="frames per rank in the host-boundary phase")
+    ap.add_argument("--ring-depth", type=int, default=4)
     ap.add_argument("--qp", type=int, default=0,
                     help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()
@@ -156,6 +209,48 @@ def main():
     packets = enc.collect(*outs[(args.steps - 1) & 1])   # also raises on any per-frame error status
     enc.collect(*outs[args.steps & 1])
 
+    # ---- host boundary: what SURVEY.md 8(d)/(e) names as the real limiter.  Every rank feeds
+    # fresh host frames through the asynchronous ring (H2D inside the timed region), then the
+    # packets are gathered in frame order on rank 0 (RCCL when N > 1).  Reported beside `value`,
+    # never as `value`.
+    hb = None
+    if not args.no_host_boundary:
+        from ffmpeg_ffv2_amd import fanout
+        nf = args.host_frames
+        hb = {}
+        variants = [("pinned", True)] + ([("pageable", False)] if world == 1 else [])
+        for name, pinned in variants:
+            dt, pk_local, frame_bytes = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
+                                                      pinned, barrier)
+            if world > 1:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            hb[name] = {"Mpix_s": round(world * nf * W * H / dt / 1e6, 1), "ms_per_frame_per_gpu": round(dt / nf * 1e3, 4),
+                        "h2d_GBs_per_gpu": round(nf * frame_bytes / dt / 1e9, 2)}
+            if pinned:
+                # in-order gather of every rank's packets on rank 0: frame n lives on rank n % world
+                mine = fanout.local_frames(world * nf, rank, world)
+                barrier()
+                g0 = time.perf_counter()
+                allp = fanout.gather_packets(pk_local, mine, world * nf, rank, world,
+                                             device=dev if backend == "nccl" else None)
+                barrier()
+                hb["gather_ms"] = round((time.perf_counter() - g0) * 1e3, 3)
+                if rank == 0:
+                    hb["ranks_seen"] = len({fanout.owner(n, world) for n, p in enumerate(allp) if p})
+                    hb["packets_gathered"] = sum(1 for p in allp if p)
+                    # frames cycle through the F benchmark frames: packet n of rank r == packet (n % F) of the device path
+                    hb["packets_match_device_path"] = bool(all(
+                        allp[n] == packets[(n // world) % F] for n in range(0, world * nf, world)))
+        rate = h2d_rate(dev, frame_bytes)
+        hb["h2d_copy_GBs"] = round(rate, 2)
+        hb["pinned_fraction_of_h2d_copy_rate"] = round(hb["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
+        hb["frames_per_gpu"] = nf
+        hb["ring_depth"] = args.ring_depth
+        hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "
+                      "H2D || T/E-stage || D2H on separate HIP streams; then in-order gather on rank 0")
+
     result = None
     if rank == 0:
         frames_total = world * F * args.steps
@@ -203,6 +298,8 @@ def main():
                          "estage_ms_avg": round(e_ms / max(launches, 1), 4),
                          "launches_timed": launches},
         }
+        if hb is not None:
+            result["host_boundary"] = hb
         if world == 1 and not args.no_cpu_baseline:
             # CPU baseline: the oracle (C restatement, byte-identical to the reference on
             # its known answers) on a bounded sample of the SAME frames, one host core.

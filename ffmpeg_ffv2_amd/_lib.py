@@ -12,13 +12,15 @@ EXPORTS = [
     "ffv2amd_coded_gain", "ffv2amd_range_prefix",
     "ffv2amd_encoder_set_coef_sink", "ffv2amd_profile_enable", "ffv2amd_profile_read", "ffv2amd_tstage_kernel_name",
     "ffv2amd_encoder_set_pipelined", "ffv2amd_encoder_flush", "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device", "ffv2amd_inverse_tstage_device",
+    "ffv2amd_ring_open", "ffv2amd_ring_send", "ffv2amd_ring_receive", "ffv2amd_ring_pending", "ffv2amd_ring_close",
+    "ffv2amd_host_alloc", "ffv2amd_host_free",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
     # Matroska wire step (ffv2mkv.c)
     "ffv2amd_mkv_open", "ffv2amd_mkv_write_packet", "ffv2amd_mkv_close",
 ]
 
-ERRORS = {-22: "EINVAL", -12: "ENOMEM", -5: "EIO (HIP device/runtime)", -28: "ENOSPC",
+ERRORS = {-11: "EAGAIN", -22: "EINVAL", -12: "ENOMEM", -5: "EIO (HIP device/runtime)", -28: "ENOSPC",
           -34: "ERANGE (sample exceeds bit depth / gain table)", -1: "reference would abort",
           -38: "ENOSYS (not supported)"}
 
@@ -79,6 +81,18 @@ def load():
     lib.ffv2amd_inverse_tstage_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ffv2amd_pvq_search_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p]
+    lib.ffv2amd_ring_open.argtypes = [C.c_void_p, C.c_int]
+    lib.ffv2amd_ring_send.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.c_void_p,
+                                      C.c_int64, C.c_uint]
+    lib.ffv2amd_ring_receive.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_int64), C.c_int]
+    lib.ffv2amd_ring_pending.argtypes = [C.c_void_p]
+    lib.ffv2amd_ring_close.argtypes = [C.c_void_p]
+    lib.ffv2amd_ring_close.restype = None
+    lib.ffv2amd_host_alloc.argtypes = [C.c_size_t]
+    lib.ffv2amd_host_alloc.restype = C.c_void_p
+    lib.ffv2amd_host_free.argtypes = [C.c_void_p]
+    lib.ffv2amd_host_free.restype = None
     lib.ffv2amd_coded_gain.argtypes = [C.c_int64]
     lib.ffv2amd_coded_gain.restype = C.c_uint32
     lib.ffv2amd_range_prefix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]

@@ -309,15 +309,84 @@ struct ffv2amd_encoder {
     hipEvent_t evT[2] = { nullptr, nullptr }, evE[2] = { nullptr, nullptr };
     bool evE_valid[2] = { false, false };
     uint32_t *d_codes2 = nullptr, *d_bitoff2 = nullptr;
+    int32_t *d_status2 = nullptr;
     unsigned seq = 0;
+    int seq_pb = 0;                      // hand-off buffer set of the call being issued
     std::vector<EvTriple> ev_pool;       // reused
     size_t ev_used = 0;
     double prof_t = 0, prof_e = 0;
     int prof_n = 0;
+    // asynchronous frame ring (ffv2amd_ring_*)
+    struct RingSlot {
+        uint8_t  *h_frame = nullptr, *d_frame = nullptr;    // pinned staging frame, device frame
+        uint8_t  *d_pkt = nullptr, *h_pkt = nullptr;
+        uint32_t *d_meta = nullptr, *h_meta = nullptr;      // [0] size, [1] status
+        uint32_t *d_codes = nullptr, *d_bitcnt = nullptr;
+        int32_t  *d_w = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_meta = nullptr;
+        int64_t tag = 0;
+    };
+    std::vector<RingSlot> ring;
+    int ring_head = 0, ring_count = 0;
+    hipStream_t ring_h2d = nullptr, ring_comp[2] = { nullptr, nullptr }, ring_d2h = nullptr, ring_pkt = nullptr;
+    unsigned ring_seq = 0;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return FFV2AMD_ERR_DEVICE; } } while (0)
+
+// Every entry point runs on the encoder's device and leaves the calling thread's current
+// device as it found it (a host application may drive several GPUs from one thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+extern "C" void ffv2amd_ring_close(ffv2amd_encoder *e);
+
+// T-stage + E-stage (qp == 0) of `nframes` frames: the one launch sequence behind
+// ffv2amd_encode_batch_device and the frame ring.  `st`/`se`: streams of the two stages.
+static int launch_encode_qp0(ffv2amd_encoder *e, int nframes, const void *d_frames, const int32_t *d_W,
+                             void *d_packets, size_t packet_stride, uint32_t *d_sizes, int32_t *status,
+                             uint32_t *codes, uint32_t *bitcnt, int32_t *coef, hipStream_t st, hipStream_t se,
+                             ffv2amd_encoder::EvTriple *ev)
+{
+    HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, st));
+    // the packet buffers are cleared by the T-stage itself (FFV2TStageArgs::zero)
+    FFV2TStageArgs a{};
+    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
+    a.coef = coef; a.energy = nullptr; a.codes = codes; a.bitcnt = bitcnt; a.W = d_W;
+    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
+    a.status = status;
+    a.zero = (uint32_t *)d_packets; a.zero_stride_dw = (uint32_t)(packet_stride / 4);
+    if (ev) HIPCHK(hipEventRecord(ev->a, st));
+    HIPCHK(ffv2_launch_tstage(a, st));
+    if (ev) HIPCHK(hipEventRecord(ev->b, st));
+    if (se != st) {
+        hipEvent_t join = e->evT[e->seq_pb];
+        HIPCHK(hipEventRecord(join, st));
+        HIPCHK(hipStreamWaitEvent(se, join, 0));
+    }
+    if (ev) HIPCHK(hipEventRecord(ev->d, se));
+    FFV2EStageArgs b{};
+    b.g = e->geom; b.nframes = nframes; b.codes = codes; b.bitoff = bitcnt;
+    b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
+    b.sizes = d_sizes; b.status = status;
+    b.prefix = e->d_prefix; b.prefix_len = e->prefix_len; b.slack_bits = e->slack;
+    // raw header: pix_fmt & 15 (daala_entropy.c:406), then Exp-Golomb(qp = 0) = "1"
+    b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
+    b.header_nbits = 5;
+    HIPCHK(ffv2_launch_estage_qp0(b, se));
+    if (ev) HIPCHK(hipEventRecord(ev->c, se));
+    return FFV2AMD_OK;
+}
 
 extern "C" {
 
@@ -340,8 +409,9 @@ int ffv2amd_range_prefix(int pix_fmt, int num_sb, uint8_t *out, size_t cap, int 
 void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
 {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    ffv2amd_ring_close(e);
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
@@ -355,7 +425,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     for (auto &t : e->ev_pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); (void)hipEventDestroy(t.c); (void)hipEventDestroy(t.d); }
     if (e->e_stream) { (void)hipStreamSynchronize(e->e_stream); (void)hipStreamDestroy(e->e_stream); }
     for (int i = 0; i < 2; i++) { if (e->evT[i]) (void)hipEventDestroy(e->evT[i]); if (e->evE[i]) (void)hipEventDestroy(e->evE[i]); }
-    (void)hipFree(e->d_codes2); (void)hipFree(e->d_bitoff2);
+    (void)hipFree(e->d_codes2); (void)hipFree(e->d_bitoff2); (void)hipFree(e->d_status2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -374,7 +444,8 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
         fprintf(stderr, "ffv2amd: no usable HIP device %d (found %d) -- this library has no CPU path\n", device, ndev);
         return FFV2AMD_ERR_DEVICE;
     }
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
 
     ffv2amd_encoder *e = new (std::nothrow) ffv2amd_encoder;
     if (!e) return FFV2AMD_ERR_NOMEM;
@@ -458,7 +529,8 @@ int ffv2amd_tstage_device(ffv2amd_encoder *e, int nframes, const void *d_frames,
                           int32_t *d_coef, int64_t *d_energy, void *stream)
 {
     if (!e || !d_frames || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
     HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int32_t) * nframes, s));
     FFV2TStageArgs a{};
@@ -481,25 +553,19 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (qp < 0) return FFV2AMD_ERR_INVAL;
     if (qp != 0) return FFV2AMD_ERR_UNSUPPORTED;              // packets of qp > 0 are finished on the host:
                                                               // use ffv2amd_encode_batch_to_host
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     hipStream_t s = (hipStream_t)stream;           // NULL = the HIP default stream
-    int32_t *status = d_status ? d_status : e->d_status;
     const bool pipe = e->pipelined;
     const int pb = pipe ? (int)(e->seq++ & 1u) : 0;
+    // pipelined mode keeps two calls in flight: each has its own hand-off buffers AND its own
+    // default status words (the memset / T-stage of call n+1 must not touch what the E-stage of
+    // call n still updates)
+    int32_t *status = d_status ? d_status : (pb ? e->d_status2 : e->d_status);
     uint32_t *codes = pb ? e->d_codes2 : e->d_codes, *bitcnt = pb ? e->d_bitoff2 : e->d_bitoff;
     hipStream_t se = pipe ? e->e_stream : s;       // stream of the E-stage
     if (pipe && e->evE_valid[pb])                  // the E-stage two calls ago read this hand-off buffer
         HIPCHK(hipStreamWaitEvent(s, e->evE[pb], 0));
-    HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, s));
-    // the packet buffers are cleared by the T-stage itself (FFV2TStageArgs::zero)
-
-    FFV2TStageArgs a{};
-    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
-    a.coef = nullptr; a.energy = nullptr; a.codes = codes; a.bitcnt = bitcnt; a.W = d_W;
-    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
-    a.status = status;
-    a.coef = e->coef_sink;
-    a.zero = (uint32_t *)d_packets; a.zero_stride_dw = (uint32_t)(packet_stride / 4);
     ffv2amd_encoder::EvTriple *ev = nullptr;
     if (e->profiling) {
         if (e->ev_used == e->ev_pool.size()) {
@@ -511,30 +577,15 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
                 ffv2amd_encoder::EvTriple t{};
                 HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.c));
                 HIPCHK(hipEventCreate(&t.d));
-                e->ev_pool.push_back(t);
+                try { e->ev_pool.push_back(t); } catch (...) { return FFV2AMD_ERR_NOMEM; }
             }
         }
         ev = &e->ev_pool[e->ev_used++];
-        HIPCHK(hipEventRecord(ev->a, s));
     }
-    HIPCHK(ffv2_launch_tstage(a, s));
-    if (ev) HIPCHK(hipEventRecord(ev->b, s));
-    if (pipe) {
-        HIPCHK(hipEventRecord(e->evT[pb], s));
-        HIPCHK(hipStreamWaitEvent(se, e->evT[pb], 0));
-    }
-    if (ev) HIPCHK(hipEventRecord(ev->d, se));
-
-    FFV2EStageArgs b{};
-    b.g = e->geom; b.nframes = nframes; b.codes = codes; b.bitoff = bitcnt;
-    b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
-    b.sizes = d_sizes; b.status = status;
-    b.prefix = e->d_prefix; b.prefix_len = e->prefix_len; b.slack_bits = e->slack;
-    // raw header: pix_fmt & 15 (daala_entropy.c:406), then Exp-Golomb(qp = 0) = "1"
-    b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
-    b.header_nbits = 5;
-    HIPCHK(ffv2_launch_estage_qp0(b, se));
-    if (ev) HIPCHK(hipEventRecord(ev->c, se));
+    e->seq_pb = pb;
+    int r = launch_encode_qp0(e, nframes, d_frames, d_W, d_packets, packet_stride, d_sizes, status, codes, bitcnt,
+                              e->coef_sink, s, se, ev);
+    if (r < 0) return r;
     if (pipe) {
         HIPCHK(hipEventRecord(e->evE[pb], se));
         e->evE_valid[pb] = true;
@@ -545,7 +596,8 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
 int ffv2amd_encoder_set_pipelined(ffv2amd_encoder *e, int on)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     if (on && !e->e_stream) {
         const size_t nb = (size_t)e->info.block_planes, B = (size_t)e->info.max_batch;
         HIPCHK(hipStreamCreateWithFlags(&e->e_stream, hipStreamNonBlocking));
@@ -555,6 +607,7 @@ int ffv2amd_encoder_set_pipelined(ffv2amd_encoder *e, int on)
         }
         HIPCHK(hipMalloc(&e->d_codes2, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B));
         HIPCHK(hipMalloc(&e->d_bitoff2, sizeof(uint32_t) * nb * B));
+        HIPCHK(hipMalloc(&e->d_status2, sizeof(int32_t) * B));
     }
     if (!on && e->pipelined) HIPCHK(hipStreamSynchronize(e->e_stream));
     e->pipelined = on != 0;
@@ -564,7 +617,8 @@ int ffv2amd_encoder_set_pipelined(ffv2amd_encoder *e, int on)
 int ffv2amd_encoder_flush(ffv2amd_encoder *e, void *stream)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     for (int i = 0; i < 2; i++)
         if (e->evE_valid[i]) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->evE[i], 0));
     return FFV2AMD_OK;
@@ -573,7 +627,8 @@ int ffv2amd_encoder_flush(ffv2amd_encoder *e, void *stream)
 const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *e, int nframes)
 {
     if (!e || nframes < 1) return "";
-    if (hipSetDevice(e->device) != hipSuccess) return "";
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return "";
     return ffv2_tstage_kernel_name(e->geom, nframes, e->coef_sink != nullptr);
 }
 
@@ -621,7 +676,8 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     const size_t row_bytes = (size_t)in.width * (in.depth > 8 ? 2 : 1);
     for (int p = 0; p < in.planes; p++)
         if (!data[p]) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     hipStream_t s = e->stream;
     // The caller's rows go through the pinned staging frame in slices: while slice n crosses
     // PCIe, slice n+1 is being gathered, so the upload costs max(gather, DMA) rather than their sum.
@@ -692,7 +748,8 @@ int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t
                                   void *d_frames_out, void *stream)
 {
     if (!e || !d_coef || !d_frames_out || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const FFV2Geom &g = e->geom;
     if (!e->d_inv_plane)
         HIPCHK(hipMalloc(&e->d_inv_plane, sizeof(int32_t) * (size_t)g.nsx * 64 * g.nsy * 64 * g.planes * e->info.max_batch));
@@ -705,7 +762,8 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
                               int count, int16_t *d_y, void *stream)
 {
     if (!e || !d_X || !d_y || count < 1 || K < 0) return FFV2AMD_ERR_INVAL;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     HIPCHK(ffv2_launch_pvq_vectors(d_X, stride, N, K, count, d_y, (hipStream_t)stream));
     return FFV2AMD_OK;
 }
@@ -718,7 +776,8 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
     if (!e || !d_frames || !h_packets || !h_sizes || !h_status || nframes < 1 || nframes > e->info.max_batch || qp < 0)
         return FFV2AMD_ERR_INVAL;
     const ffv2amd_info &in = e->info;
-    HIPCHK(hipSetDevice(e->device));
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     hipStream_t s = e->stream;
     const size_t nb = (size_t)in.block_planes, B = (size_t)in.max_batch;
     if (!e->d_pk_ws) {
@@ -784,6 +843,196 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
                 std::chrono::duration<double, std::milli>(t_end - t_dev).count());
     }
     return FFV2AMD_OK;
+}
+
+
+// ------------------------------------------------------------------
+// Asynchronous frame ring: avcodec_send_frame / avcodec_receive_packet shape
+// (reference encode.c:420,449 over ffv2enc.c:453).  `depth` frames in flight:
+//   stream ring_h2d   : host frame -> device frame (DMA straight from the caller's planes when
+//                       they are page-locked, else through the slot's pinned staging frame,
+//                       gathered in slices by one thread per plane)
+//   streams ring_comp : T-stage + E-stage of one frame, frames alternate between two streams
+//                       (the tail of one frame's kernels overlaps the head of the next)
+//   stream ring_d2h   : the 8 bytes {size, status}; the packet itself (size bytes, not the
+//                       capacity) comes back in receive() on ring_pkt
+// so that H2D(n+1) || T/E(n) || D2H(n-1).  Packets are delivered in send order.
+// ------------------------------------------------------------------
+void ffv2amd_ring_close(ffv2amd_encoder *e)
+{
+    if (!e || e->ring.empty()) return;
+    (void)hipSetDevice(e->device);
+    for (hipStream_t st : { e->ring_h2d, e->ring_comp[0], e->ring_comp[1], e->ring_d2h, e->ring_pkt })
+        if (st) (void)hipStreamSynchronize(st);
+    for (auto &r : e->ring) {
+        (void)hipFree(r.d_frame); (void)hipFree(r.d_pkt); (void)hipFree(r.d_meta);
+        (void)hipFree(r.d_codes); (void)hipFree(r.d_bitcnt); (void)hipFree(r.d_w);
+        if (r.h_frame) (void)hipHostFree(r.h_frame);
+        if (r.h_pkt) (void)hipHostFree(r.h_pkt);
+        if (r.h_meta) (void)hipHostFree(r.h_meta);
+        if (r.ev_h2d) (void)hipEventDestroy(r.ev_h2d);
+        if (r.ev_done) (void)hipEventDestroy(r.ev_done);
+        if (r.ev_meta) (void)hipEventDestroy(r.ev_meta);
+    }
+    e->ring.clear();
+    for (hipStream_t *st : { &e->ring_h2d, &e->ring_comp[0], &e->ring_comp[1], &e->ring_d2h, &e->ring_pkt })
+        if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+    e->ring_head = e->ring_count = 0;
+}
+
+int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
+{
+    if (!e || depth < 1 || depth > 64) return FFV2AMD_ERR_INVAL;
+    if (!e->ring.empty()) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes;
+#define RK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(hipGetLastError())); \
+    ffv2amd_ring_close(e); return FFV2AMD_ERR_DEVICE; } } while (0)
+    try { e->ring.resize((size_t)depth); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    RK(hipStreamCreateWithFlags(&e->ring_h2d, hipStreamNonBlocking));
+    RK(hipStreamCreateWithFlags(&e->ring_comp[0], hipStreamNonBlocking));
+    RK(hipStreamCreateWithFlags(&e->ring_comp[1], hipStreamNonBlocking));
+    RK(hipStreamCreateWithFlags(&e->ring_d2h, hipStreamNonBlocking));
+    RK(hipStreamCreateWithFlags(&e->ring_pkt, hipStreamNonBlocking));
+    for (auto &r : e->ring) {
+        RK(hipMalloc(&r.d_frame, in.frame_stride));
+        RK(hipMalloc(&r.d_pkt, in.packet_cap));
+        RK(hipMalloc(&r.d_meta, 16));
+        RK(hipMalloc(&r.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb));
+        RK(hipMalloc(&r.d_bitcnt, sizeof(uint32_t) * nb));
+        RK(hipMalloc(&r.d_w, sizeof(int32_t) * nb));
+        RK(hipHostMalloc(&r.h_frame, in.frame_stride, hipHostMallocDefault));
+        RK(hipHostMalloc(&r.h_pkt, in.packet_cap, hipHostMallocDefault));
+        RK(hipHostMalloc(&r.h_meta, 16, hipHostMallocDefault));
+        RK(hipEventCreateWithFlags(&r.ev_h2d, hipEventDisableTiming));
+        RK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));
+        RK(hipEventCreateWithFlags(&r.ev_meta, hipEventDisableTiming));
+    }
+#undef RK
+    e->ring_head = e->ring_count = 0;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_ring_pending(const ffv2amd_encoder *e) { return e ? e->ring_count : 0; }
+
+int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                      const int32_t *W, int64_t tag, unsigned flags)
+{
+    if (!e || !data || !linesize || e->ring.empty()) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    for (int p = 0; p < in.planes; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    if (e->ring_count == (int)e->ring.size()) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &r = e->ring[(size_t)((e->ring_head + e->ring_count) % (int)e->ring.size())];
+    const size_t row_bytes = (size_t)in.width * (in.depth > 8 ? 2 : 1);
+    hipStream_t sh = e->ring_h2d;
+    if (flags & FFV2AMD_FRAME_PINNED) {
+        // page-locked planes: the DMA engine reads the caller's rows directly
+        for (int p = 0; p < in.planes; p++) {
+            uint8_t *dst = r.d_frame + (size_t)p * in.plane_stride;
+            if (linesize[p] == (ptrdiff_t)in.row_pitch)
+                HIPCHK(hipMemcpyAsync(dst, data[p], in.row_pitch * (size_t)(in.height - 1) + row_bytes, hipMemcpyHostToDevice, sh));
+            else
+                HIPCHK(hipMemcpy2DAsync(dst, in.row_pitch, data[p], (size_t)linesize[p], row_bytes, (size_t)in.height,
+                                        hipMemcpyHostToDevice, sh));
+        }
+    } else {
+        // pageable planes: gather into the slot's pinned frame in slices, one thread per plane;
+        // each slice's DMA overlaps the gathering of the next
+        const int slice_rows = in.height > 64 ? (in.height + 7) / 8 : in.height;
+        auto upload_plane = [&](int p) -> hipError_t {
+            for (int y0 = 0; y0 < in.height; y0 += slice_rows) {
+                const int y1 = y0 + slice_rows < in.height ? y0 + slice_rows : in.height;
+                const size_t off = (size_t)p * in.plane_stride + (size_t)y0 * in.row_pitch;
+                for (int y = y0; y < y1; y++)
+                    memcpy(r.h_frame + (size_t)p * in.plane_stride + (size_t)y * in.row_pitch,
+                           data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
+                const hipError_t rc = hipMemcpyAsync(r.d_frame + off, r.h_frame + off, (size_t)(y1 - y0) * in.row_pitch,
+                                                     hipMemcpyHostToDevice, sh);
+                if (rc != hipSuccess) return rc;
+            }
+            return hipSuccess;
+        };
+        hipError_t up[4] = { hipSuccess, hipSuccess, hipSuccess, hipSuccess };
+        bool threaded = false;
+        if (in.planes > 1 && in.plane_stride >= (size_t)4 << 20) {
+            try {
+                std::vector<std::thread> helpers;
+                for (int p = 1; p < in.planes; p++)
+                    helpers.emplace_back([&, p]() { up[p] = hipSetDevice(e->device) == hipSuccess ? upload_plane(p) : hipErrorInvalidDevice; });
+                up[0] = upload_plane(0);
+                for (auto &t : helpers) t.join();
+                threaded = true;
+            } catch (...) { threaded = false; }          // no threads to be had: gather serially
+        }
+        if (!threaded)
+            for (int p = 0; p < in.planes; p++) up[p] = upload_plane(p);
+        for (int p = 0; p < in.planes; p++) HIPCHK(up[p]);
+    }
+    const int32_t *dW = nullptr;
+    if (W) {
+        HIPCHK(hipMemcpyAsync(r.d_w, W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, sh));
+        dW = r.d_w;
+    }
+    HIPCHK(hipEventRecord(r.ev_h2d, sh));
+    hipStream_t sc = e->ring_comp[e->ring_seq++ & 1u];
+    HIPCHK(hipStreamWaitEvent(sc, r.ev_h2d, 0));
+    int rc = launch_encode_qp0(e, 1, r.d_frame, dW, r.d_pkt, in.packet_cap, r.d_meta, (int32_t *)(r.d_meta + 1),
+                               r.d_codes, r.d_bitcnt, nullptr, sc, sc, nullptr);
+    if (rc < 0) return rc;
+    HIPCHK(hipEventRecord(r.ev_done, sc));
+    HIPCHK(hipStreamWaitEvent(e->ring_d2h, r.ev_done, 0));
+    HIPCHK(hipMemcpyAsync(r.h_meta, r.d_meta, 8, hipMemcpyDeviceToHost, e->ring_d2h));
+    HIPCHK(hipEventRecord(r.ev_meta, e->ring_d2h));
+    r.tag = tag;
+    e->ring_count++;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_ring_receive(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag, int wait)
+{
+    if (!e || !out || !out_size || e->ring.empty()) return FFV2AMD_ERR_INVAL;
+    if (e->ring_count == 0) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &r = e->ring[(size_t)e->ring_head];
+    if (!wait) {
+        const hipError_t q = hipEventQuery(r.ev_meta);
+        if (q == hipErrorNotReady) return FFV2AMD_ERR_AGAIN;
+        HIPCHK(q);
+    } else {
+        HIPCHK(hipEventSynchronize(r.ev_meta));
+    }
+    // the oldest frame is finished: from here on it leaves the ring whatever happens
+    e->ring_head = (e->ring_head + 1) % (int)e->ring.size();
+    e->ring_count--;
+    if (tag) *tag = r.tag;
+    const int32_t st = (int32_t)r.h_meta[1];
+    if (st < 0) return st;
+    const size_t n = r.h_meta[0];
+    if (n == 0) return FFV2AMD_ERR_DEVICE;
+    if (n > out_cap) return FFV2AMD_ERR_NOSPACE;
+    HIPCHK(hipMemcpyAsync(r.h_pkt, r.d_pkt, n, hipMemcpyDeviceToHost, e->ring_pkt));
+    HIPCHK(hipStreamSynchronize(e->ring_pkt));
+    memcpy(out, r.h_pkt, n);
+    *out_size = n;
+    return FFV2AMD_OK;
+}
+
+void *ffv2amd_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void ffv2amd_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 }  // extern "C"

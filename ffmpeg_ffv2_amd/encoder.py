@@ -197,6 +197,72 @@ class FFV2Encoder:
             stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
         _lib.check(self._lib.ffv2amd_encoder_flush(self._h, C.c_void_p(stream)), "flush")
 
+    # -- asynchronous frame ring: avcodec_send_frame / avcodec_receive_packet (encode.c:420,449) --
+    def ring_open(self, depth=4):
+        _lib.check(self._lib.ffv2amd_ring_open(self._h, depth), "ring_open")
+        self._ring_out = np.empty(self.info.packet_cap, np.uint8)
+
+    def ring_close(self):
+        self._lib.ffv2amd_ring_close(self._h)
+
+    def ring_pending(self):
+        return self._lib.ffv2amd_ring_pending(self._h)
+
+    def ring_send(self, frame, tag=0, W=None, pinned=False):
+        """frame: (P,H,W) host array (any row stride).  Returns False when the ring is full
+        (EAGAIN: receive a packet first).  pinned=True promises page-locked memory that stays
+        untouched until the frame's packet has been received."""
+        i = self.info
+        assert frame.dtype == self.dtype and frame.shape == (i.planes, i.height, i.width), (frame.dtype, frame.shape)
+        assert frame.strides[2] == self.dtype.itemsize
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(i.planes):
+            data[p] = frame[p].ctypes.data
+            ls[p] = frame[p].strides[0]
+        wp = None
+        if W is not None:
+            W = np.ascontiguousarray(W, np.int32)
+            assert W.size == i.block_planes
+            wp = W.ctypes.data_as(C.c_void_p)
+        r = self._lib.ffv2amd_ring_send(self._h, data, ls, wp, int(tag), 1 if pinned else 0)
+        if r == -11:
+            return False
+        _lib.check(r, "ring_send")
+        return True
+
+    def ring_receive(self, wait=True):
+        """-> (tag, packet bytes) of the oldest frame in flight, or None (nothing in flight /
+        wait=False and not finished yet).  A failed frame raises FFV2Error."""
+        n = C.c_size_t(0)
+        tag = C.c_int64(0)
+        r = self._lib.ffv2amd_ring_receive(self._h, self._ring_out.ctypes.data_as(C.c_void_p), self._ring_out.size,
+                                           C.byref(n), C.byref(tag), 1 if wait else 0)
+        if r == -11:
+            return None
+        _lib.check(r, "ring_receive")
+        return tag.value, self._ring_out[: n.value].tobytes()
+
+    def pinned_frames(self, count):
+        """(count,P,H,W) sample array in page-locked host memory (row stride = the device row
+        pitch), for ring_send(pinned=True).  Free with free_pinned()."""
+        i = self.info
+        nbytes = count * i.frame_stride
+        ptr = self._lib.ffv2amd_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError("ffv2amd_host_alloc(%d)" % nbytes)
+        buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        planes = buf.reshape(count, i.planes, i.plane_stride)[:, :, : i.row_pitch * i.height]
+        rows = planes.reshape(count, i.planes, i.height, i.row_pitch)
+        arr = rows.view(self.dtype)[:, :, :, : i.width]
+        self._pinned = getattr(self, "_pinned", []) + [ptr]
+        return arr
+
+    def free_pinned(self):
+        for ptr in getattr(self, "_pinned", []):
+            self._lib.ffv2amd_host_free(ptr)
+        self._pinned = []
+
     def profile(self, on=True):
         _lib.check(self._lib.ffv2amd_profile_enable(self._h, 1 if on else 0), "profile_enable")
 

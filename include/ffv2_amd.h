@@ -33,6 +33,7 @@ extern "C" {
 #define FFV2AMD_ERR_ABORT      (-1)   /* AVERROR(EPERM): the reference would av_assert0 -> abort
                                           (daala_entropy.c:336; qp > 0 only)                     */
 #define FFV2AMD_ERR_UNSUPPORTED (-38) /* AVERROR(ENOSYS)                                        */
+#define FFV2AMD_ERR_AGAIN      (-11)  /* AVERROR(EAGAIN): ring full (send) / nothing ready (receive) */
 
 /* AVPixelFormat values the reference encoder accepts (ffv2enc.c:596-601; numeric
  * values of libavutil/pixfmt.h in the reference tree, little-endian host). */
@@ -82,6 +83,17 @@ int  ffv2amd_encode_frame(ffv2amd_encoder *enc,
                           const uint8_t *const data[4], const ptrdiff_t linesize[4],
                           int qp, const int32_t *W,
                           uint8_t *out, size_t out_cap, size_t *out_size);
+
+/* Threads, streams, devices.  One thread at a time per encoder (as libavcodec calls encode2);
+ * different encoders may be used from different threads.  Every entry point selects the
+ * encoder's device for its own duration and restores the caller's current device.
+ * *_batch_device and tstage_device are ordered on the stream passed in: the frames must have
+ * been produced on that stream (or be complete).  ffv2amd_encode_frame,
+ * ffv2amd_encode_batch_to_host and the ring run on streams the encoder owns and synchronise
+ * with the host only; for encode_batch_to_host the device frames must be complete when it is
+ * called.  The encoder's internal hand-off buffers (and the default status words used when
+ * d_status == NULL) belong to one call at a time, two in pipelined mode: do not issue
+ * *_batch_device calls of one encoder on several streams at once. */
 
 /* Same step for `nframes` (<= max_batch) frames already resident in HBM in the
  * layout ffv2amd_info describes; packets stay in HBM:
@@ -141,6 +153,31 @@ int  ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *enc, int32_t *d_coef);
  * E-stage issued so far (a device-wide synchronise does too). Off by default. */
 int  ffv2amd_encoder_set_pipelined(ffv2amd_encoder *enc, int on);
 int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
+
+/* == avcodec_send_frame / avcodec_receive_packet (reference encode.c:420,449 around
+ * ffv2enc.c:453) as an asynchronous ring of `depth` frames, qp == 0: while frame n+1 crosses
+ * PCIe, frame n is transformed and coded and the packet of frame n-1 returns, each on its own
+ * HIP stream.  One thread drives a ring; packets come back in send order with the tag given at
+ * send.  encode2() itself stays one-in/one-out (the reference sets no AV_CODEC_CAP_DELAY).
+ *   ring_send    : FFV2AMD_ERR_AGAIN when `depth` frames are in flight (receive one first).
+ *                  flags & FFV2AMD_FRAME_PINNED: the planes are page-locked (ffv2amd_host_alloc,
+ *                  hipHostMalloc/hipHostRegister) and stay untouched until the frame's packet has
+ *                  been received -- the DMA engine then reads them in place; otherwise the rows
+ *                  are gathered into a pinned staging frame before send returns.
+ *   ring_receive : oldest frame in flight; FFV2AMD_ERR_AGAIN if none, or (wait == 0) not finished.
+ *                  Copies back the packet's own size, not the capacity.  A frame that fails
+ *                  (status < 0) is dropped from the ring and its error returned. */
+#define FFV2AMD_FRAME_PINNED 1u
+int   ffv2amd_ring_open(ffv2amd_encoder *enc, int depth);
+int   ffv2amd_ring_send(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                        const int32_t *W, int64_t tag, unsigned flags);
+int   ffv2amd_ring_receive(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size,
+                           int64_t *tag, int wait);
+int   ffv2amd_ring_pending(const ffv2amd_encoder *enc);
+void  ffv2amd_ring_close(ffv2amd_encoder *enc);
+/* page-locked host memory for frame pools feeding ring_send(FFV2AMD_FRAME_PINNED) */
+void *ffv2amd_host_alloc(size_t bytes);
+void  ffv2amd_host_free(void *p);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around the
  * T-stage kernel and around the E-stage kernels of every *_batch_device call.

@@ -16,6 +16,7 @@ EXPORTS = [
     "ffv2amd_host_alloc", "ffv2amd_host_free",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
+    "ffv2amd_codec_send_frame", "ffv2amd_codec_receive_packet", "ffv2amd_packet_unref",
     # Matroska wire step (ffv2mkv.c)
     "ffv2amd_mkv_open", "ffv2amd_mkv_write_packet", "ffv2amd_mkv_close",
 ]

@@ -10,11 +10,15 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef struct FFV2AMDEncCtx {      /* the role of FFV2EncCtx, ffv2enc.c:29-53 */
     ffv2amd_encoder *enc;
     ffv2amd_info info;
     uint8_t *scratch;
+    size_t scratch_cap;
+    int ring_open;
+    int verbose;                    /* FFV2AMD_VERBOSE: the reference's per-frame size line */
 } FFV2AMDEncCtx;
 
 static const int allowed_pix_fmts[] = {     /* ffv2enc.c:596-601 */
@@ -72,15 +76,32 @@ int ffv2amd_codec_init(FFV2AMDCodecContext *avctx)
         goto fail;
     if ((ret = ffv2amd_encoder_info(s->enc, &s->info)) < 0)
         goto fail;
-    s->scratch = malloc(s->info.packet_cap);
+    /* qp = global_quality > 0 packets are larger than the qp == 0 bound (ffv2amd_info) */
+    s->scratch_cap = avctx->global_quality > 0 ? s->info.packet_cap_qp : s->info.packet_cap;
+    s->scratch = malloc(s->scratch_cap);
     if (!s->scratch) {
         ret = FFV2AMD_ERR_NOMEM;
         goto fail;
     }
+    s->verbose = getenv("FFV2AMD_VERBOSE") != NULL;
     return 0;
 fail:
     ffv2amd_codec_close(avctx);
     return ret;
+}
+
+/* the encoder owns the payload and hands it over (daala_entropy.c:727-732) */
+static int hand_over(FFV2AMDEncCtx *s, FFV2AMDPacket *avpkt, size_t n, int64_t pts)
+{
+    avpkt->data = malloc(n ? n : 1);
+    if (!avpkt->data)
+        return FFV2AMD_ERR_NOMEM;
+    memcpy(avpkt->data, s->scratch, n);
+    avpkt->size = (int)n;
+    avpkt->pts = avpkt->dts = pts;                              /* encode.c:329-330 */
+    if (s->verbose)
+        fprintf(stderr, "Packet size = %f kib\n", n / 1024.0f);     /* ffv2enc.c:488 */
+    return 0;
 }
 
 int ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
@@ -93,21 +114,60 @@ int ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
         return FFV2AMD_ERR_INVAL;
     s = avctx->priv_data;
     *got_packet_ptr = 0;
+    if (avctx->global_quality > 0 && s->scratch_cap < s->info.packet_cap_qp) {
+        /* global_quality was raised after init: grow to the bound for any qp */
+        uint8_t *g = realloc(s->scratch, s->info.packet_cap_qp);
+        if (!g)
+            return FFV2AMD_ERR_NOMEM;
+        s->scratch = g;
+        s->scratch_cap = s->info.packet_cap_qp;
+    }
     ret = ffv2amd_encode_frame(s->enc, frame->data, frame->linesize, avctx->global_quality,
-                               NULL, s->scratch, s->info.packet_cap, &n);
+                               NULL, s->scratch, s->scratch_cap, &n);
     if (ret < 0)
         return ret;
-    /* the encoder owns the payload and hands it over (daala_entropy.c:727-732) */
-    avpkt->data = malloc(n ? n : 1);
-    if (!avpkt->data)
-        return FFV2AMD_ERR_NOMEM;
-    for (size_t i = 0; i < n; i++)
-        avpkt->data[i] = s->scratch[i];
-    avpkt->size = (int)n;
-    avpkt->pts = avpkt->dts = frame->pts;
-    fprintf(stderr, "Packet size = %f kib\n", n / 1024.0f);     /* ffv2enc.c:488 */
+    ret = hand_over(s, avpkt, n, frame->pts);
+    if (ret < 0)
+        return ret;
     *got_packet_ptr = 1;
     return 0;
+}
+
+/* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449) over the asynchronous ring:
+ * up to avctx->ring_depth frames in flight, packets in send order, pts carried as the tag.
+ * qp == 0 only (FFV2AMD_ERR_UNSUPPORTED otherwise). */
+int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *frame, unsigned flags)
+{
+    FFV2AMDEncCtx *s;
+    int ret;
+    if (!avctx || !avctx->priv_data || !frame)
+        return FFV2AMD_ERR_INVAL;
+    if (avctx->global_quality != 0)
+        return FFV2AMD_ERR_UNSUPPORTED;
+    s = avctx->priv_data;
+    if (!s->ring_open) {
+        if ((ret = ffv2amd_ring_open(s->enc, avctx->ring_depth > 0 ? avctx->ring_depth : 4)) < 0)
+            return ret;
+        s->ring_open = 1;
+    }
+    return ffv2amd_ring_send(s->enc, frame->data, frame->linesize, NULL, frame->pts, flags);
+}
+
+int ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt, int wait)
+{
+    FFV2AMDEncCtx *s;
+    size_t n = 0;
+    int64_t pts = 0;
+    int ret;
+    if (!avctx || !avctx->priv_data || !avpkt)
+        return FFV2AMD_ERR_INVAL;
+    s = avctx->priv_data;
+    if (!s->ring_open)
+        return FFV2AMD_ERR_AGAIN;
+    ret = ffv2amd_ring_receive(s->enc, s->scratch, s->scratch_cap, &n, &pts, wait);
+    if (ret < 0)
+        return ret;
+    return hand_over(s, avpkt, n, pts);
 }
 
 void ffv2amd_packet_unref(FFV2AMDPacket *pkt)

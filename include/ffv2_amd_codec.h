@@ -29,6 +29,7 @@ typedef struct FFV2AMDCodecContext {
     int pix_fmt;            /* enum AVPixelFormat value                       */
     int global_quality;     /* qp (ffv2enc.c:460); default 0                  */
     int hip_device;         /* extension: HIP ordinal, default 0              */
+    int ring_depth;         /* extension: frames in flight for send_frame/receive_packet, default 4 */
     void *priv_data;        /* owned by init/close                            */
 } FFV2AMDCodecContext;
 
@@ -58,6 +59,11 @@ int  ffv2amd_codec_init(FFV2AMDCodecContext *avctx);             /* ffv2enc.c:49
 int  ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
                            const FFV2AMDFrame *frame, int *got_packet_ptr);  /* :453 */
 int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:515     */
+/* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449): asynchronous, up to ring_depth
+ * frames in flight, FFV2AMD_ERR_AGAIN (= AVERROR(EAGAIN)) when full / nothing ready; packets in
+ * send order with the frame's pts.  flags: FFV2AMD_FRAME_PINNED of ffv2_amd.h.  qp == 0 only. */
+int  ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *frame, unsigned flags);
+int  ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt, int wait);
 void ffv2amd_packet_unref(FFV2AMDPacket *pkt);
 
 #ifdef __cplusplus

@@ -1,11 +1,13 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the frame fan-out / in-order packet
-gather.  The per-rank encoder is the oracle here (test-only; on the GPU node it is
-FFV2Encoder.encode_batch_device) -- what is under test is the sharding and the
-ordered gather, which are device independent."""
+"""N > 1 path: world_size-2 gloo run of the frame fan-out / in-order packet gather.
+Without a GPU (-m "not gpu") the per-rank encoder is the oracle (test-only) -- what is under
+test there is the sharding and the ordered gather, which are device independent.  With a GPU
+(-m gpu) the two ranks share cuda:0 and encode with the real FFV2Encoder through the
+asynchronous frame ring, host frames in, host packets out."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -23,17 +25,33 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nframes, q):
+def _worker(rank, world, port, nframes, q, use_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tests import oracle_lib
-    oracle = oracle_lib.load()
     seen = []
+    if use_gpu:
+        from ffmpeg_ffv2_amd import FFV2Encoder
+        enc = FFV2Encoder(W, H, FMT, device=0, max_batch=1)       # both ranks on cuda:0
+        enc.ring_open(2)
 
-    def encode_batch(ns):
-        seen.extend(ns)
-        return [oracle.encode(synth.make("S2", n, P, H, W, DEPTH), FMT) for n in ns]
+        def encode_batch(ns):
+            seen.extend(ns)
+            out, sent = [], 0
+            while len(out) < len(ns):
+                while sent < len(ns) and enc.ring_send(synth.make("S2", ns[sent], P, H, W, DEPTH), tag=ns[sent]):
+                    sent += 1
+                tag, pk = enc.ring_receive()
+                assert tag == ns[len(out)]
+                out.append(pk)
+            return out
+    else:
+        from tests import oracle_lib
+        oracle = oracle_lib.load()
+
+        def encode_batch(ns):
+            seen.extend(ns)
+            return [oracle.encode(synth.make("S2", n, P, H, W, DEPTH), FMT) for n in ns]
 
     out = fanout.encode_sequence(encode_batch, nframes, rank, world, batch=2)
     assert seen == fanout.local_frames(nframes, rank, world)
@@ -45,11 +63,11 @@ def _worker(rank, world, port, nframes, q):
     dist.destroy_process_group()
 
 
-def _run(world, nframes):
+def _run(world, nframes, use_gpu=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q, use_gpu)) for r in range(world)]
     for p in procs:
         p.start()
     out = q.get(timeout=120)
@@ -62,6 +80,15 @@ def _run(world, nframes):
 def test_two_ranks_ordered_gather(oracle):
     nframes = 5                                   # uneven: rank 0 gets 3 frames, rank 1 gets 2
     out = _run(2, nframes)
+    assert len(out) == nframes
+    for n in range(nframes):
+        assert out[n] == oracle.encode(synth.make("S2", n, P, H, W, DEPTH), FMT), "frame %d" % n
+
+
+@pytest.mark.gpu
+def test_two_ranks_real_encoder_shared_gpu(oracle):
+    nframes = 7
+    out = _run(2, nframes, use_gpu=True)
     assert len(out) == nframes
     for n in range(nframes):
         assert out[n] == oracle.encode(synth.make("S2", n, P, H, W, DEPTH), FMT), "frame %d" % n

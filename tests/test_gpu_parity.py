@@ -405,7 +405,8 @@ def test_avcodec_shaped_shim(oracle):
 
     class Ctx(C.Structure):
         _fields_ = [("width", C.c_int), ("height", C.c_int), ("pix_fmt", C.c_int),
-                    ("global_quality", C.c_int), ("hip_device", C.c_int), ("priv_data", C.c_void_p)]
+                    ("global_quality", C.c_int), ("hip_device", C.c_int), ("ring_depth", C.c_int),
+                    ("priv_data", C.c_void_p)]
 
     class Frame(C.Structure):
         _fields_ = [("data", C.c_void_p * 4), ("linesize", C.c_ssize_t * 4), ("pts", C.c_int64)]
@@ -414,7 +415,7 @@ def test_avcodec_shaped_shim(oracle):
         _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_int), ("pts", C.c_int64), ("dts", C.c_int64)]
 
     lib = _lib.load()
-    ctx = Ctx(320, 240, 5, 0, 0, None)
+    ctx = Ctx(320, 240, 5, 0, 0, 0, None)
     assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
     for n in range(3):
         fr = synth.noise(n, 3, 240, 320, 8)
@@ -429,8 +430,43 @@ def test_avcodec_shaped_shim(oracle):
         assert got.value == 1 and pkt.pts == 40 + n and pkt.dts == 40 + n
         assert bytes(pkt.data[: pkt.size]) == oracle.encode(fr, "yuv444p")
         lib.ffv2amd_packet_unref(C.byref(pkt))
+    # send_frame / receive_packet (encode.c:420,449): three in flight, EAGAIN on the fourth, pts as tag
+    frames = [synth.noise(10 + n, 3, 240, 320, 8) for n in range(5)]
+
+    def frame_of(fr, pts):
+        f = Frame()
+        for p in range(3):
+            f.data[p] = fr[p].ctypes.data
+            f.linesize[p] = fr[p].strides[0]
+        f.pts = pts
+        return f
+
+    ctx.ring_depth = 3
+    for n in range(3):
+        assert lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(frames[n], 70 + n)), 0) == 0
+    assert lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(frames[3], 73)), 0) == -11
+    sent = 3
+    for n in range(5):
+        pkt = Packet()
+        assert lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(pkt), 1) == 0
+        assert pkt.pts == 70 + n and bytes(pkt.data[: pkt.size]) == oracle.encode(frames[n], "yuv444p")
+        lib.ffv2amd_packet_unref(C.byref(pkt))
+        if sent < 5:
+            assert lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(frames[sent], 70 + sent)), 0) == 0
+            sent += 1
+    assert lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(Packet()), 1) == -11
     assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0 and not ctx.priv_data
-    bad = Ctx(320, 240, 0, 0, 0, None)                     # yuv420p is not accepted (ffv2enc.c:596-601)
+    # global_quality > 0 through the same surface: the packet exceeds the qp == 0 bound
+    # (parity unpinned for qp > 0: the oracle restates the PVQ asm, nothing in the reference pins it)
+    q = Ctx(320, 240, 5, 16, 0, 0, None)
+    assert lib.ffv2amd_codec_init(C.byref(q)) == 0
+    fr = synth.noise(3, 3, 240, 320, 8)
+    pkt, got = Packet(), C.c_int(0)
+    assert lib.ffv2amd_codec_encode2(C.byref(q), C.byref(pkt), C.byref(frame_of(fr, 5)), C.byref(got)) == 0
+    assert got.value == 1 and bytes(pkt.data[: pkt.size]) == oracle.encode(fr, "yuv444p", qp=16)
+    lib.ffv2amd_packet_unref(C.byref(pkt))
+    assert lib.ffv2amd_codec_close(C.byref(q)) == 0
+    bad = Ctx(320, 240, 0, 0, 0, 0, None)                  # yuv420p is not accepted (ffv2enc.c:596-601)
     assert lib.ffv2amd_codec_init(C.byref(bad)) == -22
 
 

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -254,6 +255,135 @@ int encode_frame_host_qp(const ffv2amd_info &in, int qp, const uint32_t *codes, 
     return e.finish(out, cap, size);
 }
 
+// Adaptive CDF row of n <= 16*NV symbols as NV vectors of 16 x uint16: the update
+// (daala_entropy.c:434-439: halve past 32767, then += inc from the coded symbol on) is two vector
+// operations per 16 entries instead of a scalar loop.  Entries past n-1 are never read.
+typedef uint16_t v16u __attribute__((vector_size(32)));
+typedef int16_t v16s __attribute__((vector_size(32)));
+
+template <int NV>
+struct AdaptRow {
+    alignas(32) uint16_t c[16 * NV];
+    void init() { for (int i = 0; i < 16 * NV; i++) c[i] = (uint16_t)(i + 1); }   // daalaent_cdf_alloc(..., 0, 6, 0)
+    inline void update(int n, int inc, int val)
+    {
+        v16u *v = reinterpret_cast<v16u *>(c);
+        const bool halve = c[n - 1] + inc > 32767;
+        for (int k = 0; k < NV; k++) {
+            v16s idx;
+            for (int i = 0; i < 16; i++) idx[i] = (int16_t)(16 * k + i);
+            if (halve) v[k] = (v[k] >> 1) + (v16u)(idx + 1);
+            const v16s ge = idx >= (int16_t)val;                 // all-ones lanes from the coded symbol on
+            v[k] += (v16u)(ge & (int16_t)inc);
+        }
+    }
+};
+
+// Same packet as encode_frame_host_qp, fed from the device's compact symbol stream (int8 pulses,
+// only those the coder reads: ffv2_compact_kernel) and with the vectorised CDF rows.
+template <int NV>
+int encode_frame_host_compact(const ffv2amd_info &in, int qp, const uint32_t *codes, const FFV2SymRec *rec,
+                              const int8_t *stream, uint8_t *out, size_t cap, size_t *size)
+{
+    PacketEnc e;
+    const int nsb = in.num_sb_x * in.num_sb_y;
+    try {
+        e.rc.pre.reserve((size_t)nsb * in.planes * 256 + 1024);
+        e.raw.reserve((size_t)nsb * in.planes * 96 + 1024);
+    } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    {
+        const uint32_t s = (uint32_t)in.pix_fmt >> 4;
+        auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
+        e.rc.encode(s ? q15(s) : 0, q15(s + 1), 32768);
+        e.bits((uint32_t)in.pix_fmt & 15u, 4);
+        e.golomb((uint32_t)qp);
+    }
+    uint16_t subdiv[4] = { 32, 64, 96, 128 };
+    AdaptRow<NV> row[13];
+    for (auto &r : row) r.init();
+    for (int sb = 0; sb < nsb && !e.abort_; sb++) {
+        e.adapt(subdiv, 4, 128, 0);
+        e.bits(0, 4);
+        for (int p = 0; p < in.planes && !e.abort_; p++) {
+            const size_t bp = (size_t)sb * in.planes + p;
+            const uint32_t *cr = codes + bp * FFV2_CODES_PER_BP;
+            const FFV2SymRec &sr = rec[bp];
+            const int8_t *sy = stream + sr.offset;
+            const int c0 = (int)cr[0];
+            e.golomb(c0 < 0 ? (uint32_t)(-(int64_t)c0) : (uint32_t)c0);
+            if (c0) e.bits(c0 < 0, 1);
+            for (int b = 0; b < 13 && !e.abort_; b++) {
+                e.golomb(cr[1 + b]);
+                AdaptRow<NV> &r = row[b];
+                const int len = sr.count[b];
+                // the coder's state in locals for the length of the band: the CDF stores below
+                // are uint16 writes the compiler must otherwise assume to alias it
+                uint64_t low = e.rc.low;
+                uint32_t rng = e.rc.rng;
+                int cnt = e.rc.cnt;
+                bool bad = false;
+                for (int j = 0; j < len; j++) {
+                    const int q = sy[j], aq = q < 0 ? -q : q;
+                    if (aq >= qp) { bad = true; break; }                         // daala_entropy.c:336
+                    uint32_t fl = aq ? r.c[aq - 1] : 0, fh = r.c[aq], ft = r.c[qp - 1];
+                    if (!(fl < fh && fh <= ft && ft >= 2 && ft <= 32768)) { bad = true; break; }
+                    int sc = 15 - RangeEnc::ilog(ft - 1);
+                    if ((ft << sc) > rng) { bad = true; break; }                 // :364
+                    // interval update, daala_entropy.c:362-378 (RangeEnc::encode)
+                    sc += (rng - (ft << sc)) >= (ft << sc);
+                    fl <<= sc; fh <<= sc; ft <<= sc;
+                    const uint32_t d = rng - ft;
+                    const uint32_t g = 2 * d > ft ? 2 * d - ft : 0;
+                    const uint32_t bl = (fl > g ? fl - g : 0) >> 1, bh = (fh > g ? fh - g : 0) >> 1;
+                    const uint32_t u = fl + (fl < g ? fl : g) + (bl < d ? bl : d);
+                    const uint32_t v = fh + (fh < g ? fh : g) + (bh < d ? bh : d);
+                    // renormalisation, daala_entropy.c:107-151 (RangeEnc::renorm)
+                    uint64_t l = low + u;
+                    const uint32_t rr = v - u;
+                    const int dd = 16 - RangeEnc::ilog(rr);
+                    int c = cnt, sh = c + dd;
+                    if (sh >= 0) {
+                        c += 16;
+                        uint64_t m = ((uint64_t)1 << c) - 1;
+                        if (sh >= 8) { e.rc.pre.push_back((uint16_t)(l >> c)); l &= m; c -= 8; m >>= 8; }
+                        e.rc.pre.push_back((uint16_t)(l >> c));
+                        sh = c + dd - 24;
+                        l &= m;
+                    }
+                    low = l << dd; rng = rr << dd; cnt = sh;
+                    r.update(qp, 64, aq);
+                    if (q) e.bits(q < 0, 1);
+                }
+                e.rc.low = low; e.rc.rng = rng; e.rc.cnt = cnt;
+                if (bad) e.abort_ = true;
+                sy += len;
+            }
+        }
+    }
+    if (e.abort_) return FFV2AMD_ERR_ABORT;
+    return e.finish(out, cap, size);
+}
+
+// fn(i) for i in [0, n) on up to `want` host threads (never more than the machine has);
+// falls back to the calling thread alone if threads cannot be created.
+template <class Fn>
+void run_parallel(int n, int want, Fn fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    int nt = want < n ? want : n;
+    if (nt > (int)hw) nt = (int)hw;
+    if (nt > 64) nt = 64;
+    std::atomic<int> next(0);
+    auto worker = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+    } catch (...) { /* run with what we have */ }
+    worker();
+    for (auto &t : pool) t.join();
+}
+
 int pixfmt_info(int pix_fmt, int *planes, int *depth)
 {
     switch (pix_fmt) {                    // allowed_pix_fmts, ffv2enc.c:596-601
@@ -316,6 +446,23 @@ struct ffv2amd_encoder {
     size_t ev_used = 0;
     double prof_t = 0, prof_e = 0;
     int prof_n = 0;
+    // qp > 0 pipeline (ffv2amd_qp_submit / _finish): two sets, so that the host coder of batch n
+    // runs while the GPU works on batch n+1
+    struct QpSet {
+        FFV2SymRec *d_rec = nullptr, *h_rec = nullptr;
+        int8_t *d_stream = nullptr, *h_stream = nullptr;
+        uint32_t *d_totals = nullptr, *h_totals = nullptr;
+        uint32_t *d_codes = nullptr, *h_codes = nullptr;
+        int32_t *d_status = nullptr, *h_status = nullptr;
+        hipEvent_t ev = nullptr;
+        std::vector<hipEvent_t> ev_frame;
+        int nframes = 0, qp = 0;
+        bool busy = false;
+    };
+    QpSet qset[2];
+    size_t q_stream_stride = 0;
+    hipStream_t q_copy = nullptr;
+    unsigned q_sub = 0, q_fin = 0;
     // asynchronous frame ring (ffv2amd_ring_*)
     struct RingSlot {
         uint8_t  *h_frame = nullptr, *d_frame = nullptr;    // pinned staging frame, device frame
@@ -412,6 +559,17 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     ffv2amd_ring_close(e);
+    for (auto &q : e->qset) {
+        (void)hipFree(q.d_rec); (void)hipFree(q.d_stream); (void)hipFree(q.d_totals); (void)hipFree(q.d_codes); (void)hipFree(q.d_status);
+        if (q.h_rec) (void)hipHostFree(q.h_rec);
+        if (q.h_stream) (void)hipHostFree(q.h_stream);
+        if (q.h_totals) (void)hipHostFree(q.h_totals);
+        if (q.h_codes) (void)hipHostFree(q.h_codes);
+        if (q.h_status) (void)hipHostFree(q.h_status);
+        if (q.ev) (void)hipEventDestroy(q.ev);
+        for (auto ev : q.ev_frame) (void)hipEventDestroy(ev);
+    }
+    if (e->q_copy) { (void)hipStreamSynchronize(e->q_copy); (void)hipStreamDestroy(e->q_copy); }
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
@@ -768,6 +926,123 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
     return FFV2AMD_OK;
 }
 
+// ------------------------------------------------------------------
+// qp > 0 as a two-stage pipeline.  submit: T-stage (coefficients kept), PVQ search, symbol
+// compaction and the small D2H copies, all asynchronous on the encoder's stream.  finish: the
+// oldest submitted batch -- waits for it, pulls each frame's compact symbol stream (its own
+// size, int8) and runs the adaptive range coder (daala_entropy.c:328-379,428-440; one serial
+// chain per frame, ffv2enc.c:461) on host threads, one frame per thread, each starting as soon
+// as its stream has arrived.  Two batches may be in flight: submit(n+1) before finish(n)
+// overlaps the host coder with the GPU.  1 <= qp <= 64.
+// ------------------------------------------------------------------
+static int qp_alloc(ffv2amd_encoder *e)
+{
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes, B = (size_t)in.max_batch;
+    if (!e->d_coef_ws) {
+        HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
+        HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
+    }
+    if (e->qset[0].d_rec) return FFV2AMD_OK;
+    e->q_stream_stride = (nb * 4097 + 255) / 256 * 256;          // every coefficient + the phantom slot, 1 byte each
+    HIPCHK(hipStreamCreateWithFlags(&e->q_copy, hipStreamNonBlocking));
+    for (auto &q : e->qset) {
+        HIPCHK(hipMalloc(&q.d_rec, sizeof(FFV2SymRec) * nb * B));
+        HIPCHK(hipMalloc(&q.d_stream, e->q_stream_stride * B));
+        HIPCHK(hipMalloc(&q.d_totals, sizeof(uint32_t) * B));
+        HIPCHK(hipMalloc(&q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B));
+        HIPCHK(hipMalloc(&q.d_status, sizeof(int32_t) * B));
+        HIPCHK(hipHostMalloc(&q.h_rec, sizeof(FFV2SymRec) * nb * B, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_stream, e->q_stream_stride * B, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_totals, sizeof(uint32_t) * B, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_status, sizeof(int32_t) * B, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        try { q.ev_frame.resize(B); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+        for (auto &ev : q.ev_frame) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qp_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W)
+{
+    if (!e || !d_frames || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
+    if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    int r = qp_alloc(e);
+    if (r < 0) return r;
+    auto &q = e->qset[e->q_sub & 1u];
+    if (q.busy) return FFV2AMD_ERR_AGAIN;                        // two batches already in flight
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes;
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemsetAsync(q.d_status, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(q.d_totals, 0, sizeof(uint32_t) * nframes, s));
+    FFV2TStageArgs a{};
+    a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
+    a.coef = e->d_coef_ws; a.energy = nullptr; a.codes = q.d_codes; a.bitcnt = e->d_bitoff; a.W = d_W;
+    a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan; a.status = q.d_status;
+    HIPCHK(ffv2_launch_tstage(a, s));
+    HIPCHK(ffv2_launch_pvq(e->d_coef_ws, d_W, e->d_y, qp, (long long)nb * nframes, s));
+    HIPCHK(ffv2_launch_compact(e->d_y, qp, (int)nb, nframes, q.d_rec, q.d_stream, e->q_stream_stride, q.d_totals, s));
+    HIPCHK(hipMemcpyAsync(q.h_totals, q.d_totals, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(q.h_status, q.d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(q.h_rec, q.d_rec, sizeof(FFV2SymRec) * nb * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(q.h_codes, q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(q.ev, s));
+    q.nframes = nframes; q.qp = qp; q.busy = true;
+    e->q_sub++;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qp_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t packet_stride, uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !h_packets || !h_sizes || !h_status) return FFV2AMD_ERR_INVAL;
+    if (e->q_fin == e->q_sub) return FFV2AMD_ERR_AGAIN;          // nothing submitted
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &q = e->qset[e->q_fin & 1u];
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes;
+    const int nframes = q.nframes, qp = q.qp;
+    HIPCHK(hipEventSynchronize(q.ev));
+    // each frame's symbol stream: its own size, on the copy stream, one event per frame
+    for (int f = 0; f < nframes; f++) {
+        h_status[f] = q.h_status[f];
+        h_sizes[f] = 0;
+        if (h_status[f] < 0) continue;
+        if (q.h_totals[f] > e->q_stream_stride) { h_status[f] = FFV2AMD_ERR_DEVICE; continue; }
+        HIPCHK(hipMemcpyAsync(q.h_stream + (size_t)f * e->q_stream_stride, q.d_stream + (size_t)f * e->q_stream_stride,
+                              q.h_totals[f], hipMemcpyDeviceToHost, e->q_copy));
+        HIPCHK(hipEventRecord(q.ev_frame[(size_t)f], e->q_copy));
+    }
+    const int device = e->device;
+    run_parallel(nframes, nframes, [&](int f) {
+        if (h_status[f] < 0) return;
+        if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(q.ev_frame[(size_t)f]) != hipSuccess) {
+            h_status[f] = FFV2AMD_ERR_DEVICE;
+            return;
+        }
+        size_t n = 0;
+        const uint32_t *codes = q.h_codes + (size_t)f * nb * FFV2_CODES_PER_BP;
+        const FFV2SymRec *rec = q.h_rec + (size_t)f * nb;
+        const int8_t *st = q.h_stream + (size_t)f * e->q_stream_stride;
+        uint8_t *out = h_packets + (size_t)f * packet_stride;
+        int r;
+        try {
+            r = qp <= 16 ? encode_frame_host_compact<1>(in, qp, codes, rec, st, out, packet_stride, &n)
+              : qp <= 32 ? encode_frame_host_compact<2>(in, qp, codes, rec, st, out, packet_stride, &n)
+                         : encode_frame_host_compact<4>(in, qp, codes, rec, st, out, packet_stride, &n);
+        } catch (...) { r = FFV2AMD_ERR_NOMEM; }
+        h_status[f] = r;
+        h_sizes[f] = r < 0 ? 0 : (uint32_t)n;
+    });
+    q.busy = false;
+    e->q_fin++;
+    return FFV2AMD_OK;
+}
+
 int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_frames,
                                  int qp, const int32_t *d_W,
                                  uint8_t *h_packets, size_t packet_stride,
@@ -801,11 +1076,20 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
         }
         return FFV2AMD_OK;
     }
+    if (qp <= 64) {
+        if (e->q_fin != e->q_sub) return FFV2AMD_ERR_INVAL;      // a submitted batch is still waiting for its finish
+        int r = ffv2amd_qp_submit(e, nframes, d_frames, qp, d_W);
+        if (r < 0) return r;
+        return ffv2amd_qp_finish(e, h_packets, packet_stride, h_sizes, h_status);
+    }
     const auto t_begin = std::chrono::steady_clock::now();
-    // qp > 0: T-stage with coefficients kept, PVQ search, then the host range coder
+    // qp > 64: pulses no longer fit the compact int8 stream / the vectorised CDF rows: the plain
+    // path -- T-stage with coefficients kept, PVQ search, every int16 pulse to the host
     if (!e->d_coef_ws) {
         HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
         HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
+    }
+    if (!e->h_y) {
         HIPCHK(hipHostMalloc(&e->h_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&e->h_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * B, hipHostMallocDefault));
     }
@@ -823,19 +1107,18 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
     HIPCHK(hipStreamSynchronize(s));
     const bool trace = getenv("FFV2AMD_TRACE") != nullptr;
     const auto t_dev = std::chrono::steady_clock::now();
-    std::vector<std::thread> pool;
-    for (int f = 0; f < nframes; f++) {
-        if (h_status[f] < 0) { h_sizes[f] = 0; continue; }
-        pool.emplace_back([=, &in]() {
-            size_t n = 0;
-            int r = encode_frame_host_qp(in, qp, e->h_codes + (size_t)f * nb * FFV2_CODES_PER_BP,
-                                         e->h_y + (size_t)f * nb * FFV2_Y_STRIDE,
-                                         h_packets + (size_t)f * packet_stride, packet_stride, &n);
-            h_status[f] = r;
-            h_sizes[f] = r < 0 ? 0 : (uint32_t)n;
-        });
-    }
-    for (auto &t : pool) t.join();
+    run_parallel(nframes, nframes, [&](int f) {
+        if (h_status[f] < 0) { h_sizes[f] = 0; return; }
+        size_t n = 0;
+        int r;
+        try {
+            r = encode_frame_host_qp(in, qp, e->h_codes + (size_t)f * nb * FFV2_CODES_PER_BP,
+                                     e->h_y + (size_t)f * nb * FFV2_Y_STRIDE,
+                                     h_packets + (size_t)f * packet_stride, packet_stride, &n);
+        } catch (...) { r = FFV2AMD_ERR_NOMEM; }
+        h_status[f] = r;
+        h_sizes[f] = r < 0 ? 0 : (uint32_t)n;
+    });
     if (trace) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "ffv2amd: qp=%d batch of %d: device (T-stage + PVQ + copies) %.3f ms, host range coder %.3f ms\n",

@@ -56,6 +56,15 @@ hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s);
 const char *ffv2_tstage_kernel_name(const FFV2Geom &g, int nframes, bool coef_writeback);   // which T-stage kernel a launch would use
 hipError_t ffv2_launch_inverse(const FFV2Geom &g, int nframes, const int32_t *coef, int32_t *plane,
                                uint8_t *frames, const uint16_t *lds_scan, hipStream_t s);
+// Per-block-plane index into a frame's compact symbol stream (qp > 0): the int8 pulses the
+// range coder will read, band after band, start at stream[offset]; count[b] of them in band b.
+struct FFV2SymRec {
+    uint32_t offset;
+    uint16_t count[FFV2_NUM_BANDS];
+    uint16_t pad;
+};
+hipError_t ffv2_launch_compact(const int16_t *y, int qp, int nblk, int nframes, FFV2SymRec *rec, int8_t *stream,
+                               size_t stream_stride, uint32_t *totals, hipStream_t s);
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s);
 hipError_t ffv2_launch_pvq_vectors(const float *X, int stride, int N, int K, int count, int16_t *y, hipStream_t s);
 hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s);

@@ -213,7 +213,68 @@ __global__ __launch_bounds__(64) void ffv2_pvq_vectors_kernel(const float *X, in
     pvq_search_wave<33>(x, N, K, L, lane, yv);
 }
 
+// ---------------------------------------------------------------------------
+// Symbol compaction for the host range coder (qp > 0).  The coder reads a band's pulses only
+// until their magnitudes add up to qp (ffv2enc.c:176-186), so everything behind that point --
+// and the upper byte of every int16 -- never has to cross PCIe.  One wavefront per block-plane:
+// per band the number of symbols the coder will read, then the symbols themselves as int8 into
+// a per-frame stream at an offset reserved with one atomic add.  The stream's order is whatever
+// order the workgroups arrive in; the per-block-plane record {offset, 13 counts} indexes it.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ffv2_compact_kernel(const int16_t *y, int qp, int nblk, FFV2SymRec *rec,
+                                                          int8_t *stream, size_t stream_stride, uint32_t *totals)
+{
+    const int f = blockIdx.y, bp = blockIdx.x, lane = threadIdx.x;
+    const int16_t *yy = y + ((size_t)f * nblk + bp) * FFV2_Y_STRIDE;
+    uint32_t cnt[FFV2_NUM_BANDS];
+    uint32_t total = 0;
+#pragma unroll 1
+    for (int b = 0; b < FFV2_NUM_BANDS; b++) {
+        const int lo = 1 + PVQ_BS[b], N = PVQ_BS[b + 1] - PVQ_BS[b];
+        // first j with |y_0| + ... + |y_j| >= qp, walking the band in rows of 64
+        int run = 0, stop = N;
+        for (int j0 = 0; j0 < N && stop == N; j0 += 64) {
+            const int j = j0 + lane;
+            int a = j < N ? yy[lo + j] : 0;
+            a = a < 0 ? -a : a;
+            int incl = a;                                      // inclusive prefix over the row
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const unsigned long long hit = __ballot(run + incl >= qp);
+            if (hit) stop = j0 + __ffsll((long long)hit);      // 1-based position -> count
+            run += __shfl(incl, 63, 64);
+        }
+        if (stop > N) stop = N;
+        cnt[b] = (uint32_t)stop;
+        total += (uint32_t)stop;
+    }
+    uint32_t off = 0;
+    if (lane == 0) off = atomicAdd(&totals[f], total);
+    off = (uint32_t)__shfl((int)off, 0, 64);
+    FFV2SymRec *r = rec + (size_t)f * nblk + bp;
+    if (lane == 0) r->offset = off;
+    int8_t *dst = stream + (size_t)f * stream_stride + off;
+#pragma unroll 1
+    for (int b = 0; b < FFV2_NUM_BANDS; b++) {
+        const int lo = 1 + PVQ_BS[b];
+        if (lane == 0) r->count[b] = (uint16_t)cnt[b];
+        for (uint32_t j = (uint32_t)lane; j < cnt[b]; j += 64) dst[j] = (int8_t)yy[lo + j];
+        dst += cnt[b];
+    }
+}
+
 }  // namespace
+
+hipError_t ffv2_launch_compact(const int16_t *y, int qp, int nblk, int nframes, FFV2SymRec *rec, int8_t *stream,
+                               size_t stream_stride, uint32_t *totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(ffv2_compact_kernel, dim3((unsigned)nblk, (unsigned)nframes), dim3(64), 0, s,
+                       y, qp, nblk, rec, stream, stream_stride, totals);
+    return hipGetLastError();
+}
 
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s)
 {

@@ -142,6 +142,33 @@ class FFV2Encoder:
                 raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
         return [pk[f, : sizes[f]].tobytes() for f in range(F)]
 
+    def qp_submit(self, d_frames, qp, d_W=None):
+        """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
+        r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
+                                        d_W.data_ptr() if d_W is not None else None)
+        if r == -11:
+            return False
+        _lib.check(r, "ffv2amd_qp_submit")
+        self._qp_frames = getattr(self, "_qp_frames", []) + [d_frames.shape[0]]
+        return True
+
+    def qp_finish(self):
+        """Host half of the oldest submitted batch -> list of packets (bytes)."""
+        F = self._qp_frames.pop(0)
+        cap = self.info.packet_cap_qp
+        if getattr(self, "_qp_out", None) is None or self._qp_out.shape[0] < F:
+            self._qp_out = np.empty((F, cap), np.uint8)
+        pk = self._qp_out
+        sizes = np.zeros(F, np.uint32)
+        status = np.zeros(F, np.int32)
+        _lib.check(self._lib.ffv2amd_qp_finish(self._h, pk.ctypes.data_as(C.c_void_p), cap,
+                                               sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)),
+                   "ffv2amd_qp_finish")
+        for f in range(F):
+            if status[f] < 0:
+                raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
+        return [pk[f, : sizes[f]].tobytes() for f in range(F)]
+
     def inverse_tstage(self, d_coef):
         """Decoder-side inverse of the T-stage: torch int32 (F, block_planes, 4096) ->
         torch uint8 (F, frame_stride) in the device frame layout."""

@@ -127,6 +127,17 @@ int  ffv2amd_encode_batch_to_host(ffv2amd_encoder *enc, int nframes, const void 
                                   uint8_t *h_packets, size_t packet_stride,
                                   uint32_t *h_sizes, int32_t *h_status);
 
+/* The same batch step for 1 <= qp <= 64 split in two, so that consecutive batches overlap:
+ *   qp_submit : T-stage, PVQ search and symbol compaction of one batch, asynchronous on the
+ *               encoder's stream (frames must be complete when it is called); at most two
+ *               batches in flight (FFV2AMD_ERR_AGAIN beyond that).
+ *   qp_finish : oldest submitted batch -> packets in host memory; runs the range coder on host
+ *               threads, one frame per thread.  FFV2AMD_ERR_AGAIN when nothing is submitted.
+ * submit(n+1) issued before finish(n) hides the GPU work behind the host coder. */
+int  ffv2amd_qp_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
+int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
+                       uint32_t *h_sizes, int32_t *h_status);
+
 /* Decoder-side inverse of the T-stage (reference ffv2.c:81-98 coding_to_raster, :4962-4972
  * tx_inv_2d / od_bin_idct64, :216-239 lapping post-filter in ffv2dec.c's seam order,
  * :40-52 coeffs_2_ref): coding-order coefficients d_coef[nframes][block_planes][4096] ->

@@ -7,6 +7,9 @@
  *
  *   ffv2enc_cli WIDTH HEIGHT PIX_FMT IN.yuv OUT.ffv2 [QP] [HIP_DEVICE]
  *   PIX_FMT: gray | yuv444p | yuv444p10le | yuv444p12le | gbrp | gbrp10le | gbrp12le
+ *            yuv420p | yuv420p10le | yuv420p12le are converted first, as the ffmpeg tool does
+ *            (choose_pixel_fmt -> yuv444p* + auto-inserted bicubic scale filter); --no-convert
+ *            as a last argument hands them to encode2 unconverted, which refuses them (exit 2).
  * An output name ending in ".mkv" selects the Matroska writer (include/ffv2_amd_mkv.h,
  * "V_FFV2", 25 frames per second) instead of the back-to-back packet stream.
  */
@@ -18,8 +21,15 @@
 #include "ffv2_amd_codec.h"
 #include "ffv2_amd_mkv.h"
 
-static int parse_fmt(const char *s, int *planes, int *bps)
+static int parse_fmt(const char *s, int *planes, int *bps, int *is420)
 {
+    static const struct { const char *n; int id, bps; } sub[] = {
+        { "yuv420p", FFV2AMD_PIX_YUV444P, 1 }, { "yuv420p10le", FFV2AMD_PIX_YUV444P10LE, 2 },
+        { "yuv420p12le", FFV2AMD_PIX_YUV444P12LE, 2 },
+    };
+    *is420 = 0;
+    for (size_t i = 0; i < sizeof(sub) / sizeof(sub[0]); i++)
+        if (!strcmp(s, sub[i].n)) { *planes = 3; *bps = sub[i].bps; *is420 = 1; return sub[i].id; }
     static const struct { const char *n; int id, planes, bps; } tab[] = {
         { "gray", FFV2AMD_PIX_GRAY8, 1, 1 },           { "yuv444p", FFV2AMD_PIX_YUV444P, 3, 1 },
         { "gbrp", FFV2AMD_PIX_GBRP, 3, 1 },            { "yuv444p10le", FFV2AMD_PIX_YUV444P10LE, 3, 2 },
@@ -37,14 +47,18 @@ int main(int argc, char **argv)
         fprintf(stderr, "usage: %s WIDTH HEIGHT PIX_FMT IN.yuv OUT.ffv2 [QP] [HIP_DEVICE]\n", argv[0]);
         return 2;
     }
-    int planes = 0, bps = 0;
+    int planes = 0, bps = 0, is420 = 0;
     FFV2AMDCodecContext ctx = { 0 };
     ctx.width = atoi(argv[1]);
     ctx.height = atoi(argv[2]);
-    ctx.pix_fmt = parse_fmt(argv[3], &planes, &bps);
+    ctx.pix_fmt = parse_fmt(argv[3], &planes, &bps, &is420);
+    if (is420 && !strcmp(argv[argc - 1], "--no-convert")) {
+        fprintf(stderr, "%s is not an encoder input (ffv2enc.c:596-601)\n", argv[3]);
+        return 2;
+    }
     ctx.global_quality = argc > 6 ? atoi(argv[6]) : 0;
     ctx.hip_device = argc > 7 ? atoi(argv[7]) : 0;
-    if (ctx.pix_fmt < 0) { fprintf(stderr, "unsupported pix_fmt %s (the encoder takes 4:4:4 planar only)\n", argv[3]); return 2; }
+    if (ctx.pix_fmt < 0) { fprintf(stderr, "unsupported pix_fmt %s\n", argv[3]); return 2; }
     FILE *in = strcmp(argv[4], "-") ? fopen(argv[4], "rb") : stdin;
     const size_t olen = strlen(argv[5]);
     const int as_mkv = olen > 4 && !strcmp(argv[5] + olen - 4, ".mkv");
@@ -56,20 +70,23 @@ int main(int argc, char **argv)
     if (ret < 0) { fprintf(stderr, "init failed: %d\n", ret); return 1; }
 
     const size_t plane_bytes = (size_t)ctx.width * ctx.height * bps;
-    uint8_t *buf = malloc(plane_bytes * planes);
+    const int cw = (ctx.width + 1) / 2, ch = (ctx.height + 1) / 2;
+    const size_t cplane_bytes = (size_t)cw * ch * bps;
+    const size_t frame_bytes = is420 ? plane_bytes + 2 * cplane_bytes : plane_bytes * planes;
+    uint8_t *buf = malloc(frame_bytes);
     if (!buf) return 1;
     long nframes = 0;
     size_t nbytes = 0;
-    while (fread(buf, 1, plane_bytes * planes, in) == plane_bytes * planes) {
+    while (fread(buf, 1, frame_bytes, in) == frame_bytes) {
         FFV2AMDFrame fr = { 0 };
         FFV2AMDPacket pkt = { 0 };
         int got = 0;
         for (int p = 0; p < planes; p++) {
-            fr.data[p] = buf + p * plane_bytes;
-            fr.linesize[p] = (ptrdiff_t)ctx.width * bps;
+            fr.data[p] = is420 ? (p ? buf + plane_bytes + (p - 1) * cplane_bytes : buf) : buf + p * plane_bytes;
+            fr.linesize[p] = (ptrdiff_t)(is420 && p ? cw : ctx.width) * bps;
         }
         fr.pts = nframes;
-        ret = ffv2amd_codec_encode2(&ctx, &pkt, &fr, &got);
+        ret = is420 ? ffv2amd_codec_encode_yuv420(&ctx, &pkt, &fr, &got) : ffv2amd_codec_encode2(&ctx, &pkt, &fr, &got);
         if (ret < 0 || !got) { fprintf(stderr, "encode2 failed on frame %ld: %d\n", nframes, ret); break; }
         if (mkv) ret = ffv2amd_mkv_write_packet(mkv, pkt.data, (size_t)pkt.size, pkt.pts);
         else     fwrite(pkt.data, 1, (size_t)pkt.size, out);

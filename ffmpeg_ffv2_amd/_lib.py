@@ -14,9 +14,10 @@ EXPORTS = [
     "ffv2amd_encoder_set_pipelined", "ffv2amd_encoder_flush", "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device", "ffv2amd_inverse_tstage_device",
     "ffv2amd_ring_open", "ffv2amd_ring_send", "ffv2amd_ring_receive", "ffv2amd_ring_pending", "ffv2amd_ring_close",
     "ffv2amd_host_alloc", "ffv2amd_host_free", "ffv2amd_qp_submit", "ffv2amd_qp_finish",
+    "ffv2amd_frame_bytes_420", "ffv2amd_upconvert_420_device", "ffv2amd_encode_frame_420",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
-    "ffv2amd_codec_send_frame", "ffv2amd_codec_receive_packet", "ffv2amd_packet_unref",
+    "ffv2amd_codec_send_frame", "ffv2amd_codec_receive_packet", "ffv2amd_packet_unref", "ffv2amd_codec_encode_yuv420",
     # Matroska wire step (ffv2mkv.c)
     "ffv2amd_mkv_open", "ffv2amd_mkv_write_packet", "ffv2amd_mkv_close",
 ]
@@ -96,6 +97,11 @@ def load():
     lib.ffv2amd_host_free.restype = None
     lib.ffv2amd_qp_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ffv2amd_qp_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.ffv2amd_frame_bytes_420.argtypes = [C.c_void_p]
+    lib.ffv2amd_frame_bytes_420.restype = C.c_size_t
+    lib.ffv2amd_upconvert_420_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ffv2amd_encode_frame_420.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.c_int,
+                                             C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ffv2amd_coded_gain.argtypes = [C.c_int64]
     lib.ffv2amd_coded_gain.restype = C.c_uint32
     lib.ffv2amd_range_prefix.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]

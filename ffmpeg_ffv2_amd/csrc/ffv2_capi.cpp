@@ -463,6 +463,10 @@ struct ffv2amd_encoder {
     size_t q_stream_stride = 0;
     hipStream_t q_copy = nullptr;
     unsigned q_sub = 0, q_fin = 0;
+    // 4:2:0 -> 4:4:4 front end (ffv2amd_*_420)
+    FFV2Upconv *upconv = nullptr;
+    bool upconv_tried = false;
+    uint8_t *d_420 = nullptr, *h_420 = nullptr;
     // asynchronous frame ring (ffv2amd_ring_*)
     struct RingSlot {
         uint8_t  *h_frame = nullptr, *d_frame = nullptr;    // pinned staging frame, device frame
@@ -497,6 +501,7 @@ struct DeviceGuard {
 };
 
 extern "C" void ffv2amd_ring_close(ffv2amd_encoder *e);
+static int encode_uploaded_frame(ffv2amd_encoder *e, int qp, const int32_t *W, uint8_t *out, size_t out_cap, size_t *out_size);
 
 // T-stage + E-stage (qp == 0) of `nframes` frames: the one launch sequence behind
 // ffv2amd_encode_batch_device and the frame ring.  `st`/`se`: streams of the two stages.
@@ -559,6 +564,9 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     ffv2amd_ring_close(e);
+    ffv2_upconv_destroy(e->upconv);
+    (void)hipFree(e->d_420);
+    if (e->h_420) (void)hipHostFree(e->h_420);
     for (auto &q : e->qset) {
         (void)hipFree(q.d_rec); (void)hipFree(q.d_stream); (void)hipFree(q.d_totals); (void)hipFree(q.d_codes); (void)hipFree(q.d_status);
         if (q.h_rec) (void)hipHostFree(q.h_rec);
@@ -870,6 +878,14 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
         for (int p = 0; p < in.planes; p++) up[p] = upload_plane(p);
     }
     for (int p = 0; p < in.planes; p++) HIPCHK(up[p]);
+    return encode_uploaded_frame(e, qp, W, out, out_cap, out_size);
+}
+
+// e->d_frame holds (or will hold, in order on e->stream) one 4:4:4 frame: encode it to `out`
+static int encode_uploaded_frame(ffv2amd_encoder *e, int qp, const int32_t *W, uint8_t *out, size_t out_cap, size_t *out_size)
+{
+    const ffv2amd_info &in = e->info;
+    hipStream_t s = e->stream;
     const int32_t *dW = nullptr;
     if (W) {
         HIPCHK(hipMemcpyAsync(e->d_w1, W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, s));
@@ -900,6 +916,69 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     memcpy(out, e->h_pkt, n);
     *out_size = n;
     return FFV2AMD_OK;
+}
+
+// ------------------------------------------------------------------
+// 4:2:0 front end: what the reference tool chain does before encode2() when handed
+// yuv420p / yuv420p10le / yuv420p12le (fftools/ffmpeg_filter.c:63-131 + the auto-inserted
+// bicubic scale filter, libswscale/utils.c:332-727) -- see ffv2_upconv.hip.  The encoder must
+// have been created for the yuv444p format of the same depth.  PARITY UNPINNED.
+// ------------------------------------------------------------------
+static int upconv_ready(ffv2amd_encoder *e)
+{
+    const ffv2amd_info &in = e->info;
+    if (in.planes != 3 || (in.pix_fmt != FFV2AMD_PIX_YUV444P && in.pix_fmt != FFV2AMD_PIX_YUV444P10LE &&
+                           in.pix_fmt != FFV2AMD_PIX_YUV444P12LE))
+        return FFV2AMD_ERR_INVAL;
+    if (!e->upconv && !e->upconv_tried) {
+        e->upconv_tried = true;
+        e->upconv = ffv2_upconv_create(in.width, in.height, in.depth);
+    }
+    return e->upconv ? FFV2AMD_OK : FFV2AMD_ERR_UNSUPPORTED;
+}
+
+size_t ffv2amd_frame_bytes_420(const ffv2amd_encoder *e)
+{
+    return e ? ffv2_upconv_src_frame_bytes(e->info.width, e->info.height, e->info.depth) : 0;
+}
+
+int ffv2amd_upconvert_420_device(ffv2amd_encoder *e, int nframes, const void *d_src420, void *d_frames444, void *stream)
+{
+    if (!e || !d_src420 || !d_frames444 || nframes < 1) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    int r = upconv_ready(e);
+    if (r < 0) return r;
+    HIPCHK(ffv2_launch_upconv(e->upconv, e->geom, nframes, (const uint8_t *)d_src420, ffv2amd_frame_bytes_420(e),
+                              (uint8_t *)d_frames444, (hipStream_t)stream));
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_encode_frame_420(ffv2amd_encoder *e, const uint8_t *const data[3], const ptrdiff_t linesize[3],
+                             int qp, uint8_t *out, size_t out_cap, size_t *out_size)
+{
+    if (!e || !data || !linesize || !out || !out_size || !data[0] || !data[1] || !data[2]) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    int r = upconv_ready(e);
+    if (r < 0) return r;
+    const ffv2amd_info &in = e->info;
+    const size_t bps = in.depth > 8 ? 2 : 1, total = ffv2amd_frame_bytes_420(e);
+    if (!e->d_420) {
+        HIPCHK(hipMalloc(&e->d_420, total));
+        HIPCHK(hipHostMalloc(&e->h_420, total, hipHostMallocDefault));
+    }
+    const int cw = (in.width + 1) >> 1, ch = (in.height + 1) >> 1;
+    uint8_t *dst = e->h_420;
+    for (int p = 0; p < 3; p++) {                                  // tight rows: Y, U, V
+        const int w = p ? cw : in.width, h = p ? ch : in.height;
+        for (int y = 0; y < h; y++, dst += (size_t)w * bps)
+            memcpy(dst, data[p] + (ptrdiff_t)y * linesize[p], (size_t)w * bps);
+    }
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->d_420, e->h_420, total, hipMemcpyHostToDevice, s));
+    HIPCHK(ffv2_launch_upconv(e->upconv, e->geom, 1, e->d_420, total, e->d_frame, s));
+    return encode_uploaded_frame(e, qp, nullptr, out, out_cap, out_size);
 }
 
 int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t *d_coef,

@@ -68,3 +68,11 @@ hipError_t ffv2_launch_compact(const int16_t *y, int qp, int nblk, int nframes, 
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s);
 hipError_t ffv2_launch_pvq_vectors(const float *X, int stride, int N, int K, int count, int16_t *y, hipStream_t s);
 hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s);
+
+// 4:2:0 -> 4:4:4 up-conversion in front of the T-stage (ffv2_upconv.hip)
+struct FFV2Upconv;
+FFV2Upconv *ffv2_upconv_create(int w, int h, int depth);
+void ffv2_upconv_destroy(FFV2Upconv *u);
+size_t ffv2_upconv_src_frame_bytes(int w, int h, int depth);
+hipError_t ffv2_launch_upconv(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src,
+                              size_t src_frame_stride, uint8_t *dst, hipStream_t s);

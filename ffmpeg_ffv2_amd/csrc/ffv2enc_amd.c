@@ -133,6 +133,34 @@ int ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
     return 0;
 }
 
+/* What the ffmpeg TOOL does around encode2() for a yuv420p / yuv420p10le / yuv420p12le source:
+ * choose_pixel_fmt() (fftools/ffmpeg_filter.c:63-131) selects yuv444p* of the same depth, the
+ * auto-inserted scale filter (flags=bicubic) converts, then encode2() runs.  avctx must have been
+ * initialised with that yuv444p* format -- encode2() itself keeps refusing 4:2:0, as the reference
+ * does (utils.c:814-822).  frame: data[0..2] = Y, U, V with their own linesizes.  PARITY UNPINNED. */
+int ffv2amd_codec_encode_yuv420(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
+                                const FFV2AMDFrame *frame, int *got_packet_ptr)
+{
+    FFV2AMDEncCtx *s;
+    size_t n = 0;
+    int ret;
+    if (!avctx || !avctx->priv_data || !avpkt || !frame || !got_packet_ptr)
+        return FFV2AMD_ERR_INVAL;
+    s = avctx->priv_data;
+    *got_packet_ptr = 0;
+    if (avctx->global_quality > 0 && s->scratch_cap < s->info.packet_cap_qp)
+        return FFV2AMD_ERR_NOSPACE;
+    ret = ffv2amd_encode_frame_420(s->enc, frame->data, frame->linesize, avctx->global_quality,
+                                   s->scratch, s->scratch_cap, &n);
+    if (ret < 0)
+        return ret;
+    ret = hand_over(s, avpkt, n, frame->pts);
+    if (ret < 0)
+        return ret;
+    *got_packet_ptr = 1;
+    return 0;
+}
+
 /* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449) over the asynchronous ring:
  * up to avctx->ring_depth frames in flight, packets in send order, pts carried as the tag.
  * qp == 0 only (FFV2AMD_ERR_UNSUPPORTED otherwise). */

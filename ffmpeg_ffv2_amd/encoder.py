@@ -142,6 +142,38 @@ class FFV2Encoder:
                 raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
         return [pk[f, : sizes[f]].tobytes() for f in range(F)]
 
+    # -- 4:2:0 front end (the reference tool's auto-inserted bicubic scale filter) --
+    def _planes420(self, y, u, v):
+        i = self.info
+        cw, ch = (i.width + 1) // 2, (i.height + 1) // 2
+        y = np.ascontiguousarray(y, self.dtype); u = np.ascontiguousarray(u, self.dtype); v = np.ascontiguousarray(v, self.dtype)
+        assert y.shape == (i.height, i.width) and u.shape == (ch, cw) and v.shape == (ch, cw), (y.shape, u.shape)
+        return y, u, v
+
+    def encode2_420(self, y, u, v, qp=0):
+        """yuv420p* host frame (Y (H,W); U, V (ceil(H/2), ceil(W/2))) -> packet bytes."""
+        y, u, v = self._planes420(y, u, v)
+        data = (C.c_void_p * 3)(y.ctypes.data, u.ctypes.data, v.ctypes.data)
+        ls = (C.c_ssize_t * 3)(y.strides[0], u.strides[0], v.strides[0])
+        out = np.empty(self.info.packet_cap if qp == 0 else self.info.packet_cap_qp, np.uint8)
+        n = C.c_size_t(0)
+        _lib.check(self._lib.ffv2amd_encode_frame_420(self._h, data, ls, qp, out.ctypes.data_as(C.c_void_p), out.size,
+                                                      C.byref(n)), "ffv2amd_encode_frame_420")
+        return out[: n.value].tobytes()
+
+    def upconvert_420(self, y, u, v):
+        """-> (3,H,W) yuv444p* samples as the GPU front end produces them."""
+        import torch
+        y, u, v = self._planes420(y, u, v)
+        src = torch.from_numpy(np.concatenate([y.reshape(-1), u.reshape(-1), v.reshape(-1)]).view(np.uint8)).to(
+            "cuda:%d" % self.device)
+        assert src.numel() == self._lib.ffv2amd_frame_bytes_420(self._h)
+        dst = torch.zeros((1, self.info.frame_stride), dtype=torch.uint8, device=src.device)
+        stream = torch.cuda.current_stream(src.device).cuda_stream
+        _lib.check(self._lib.ffv2amd_upconvert_420_device(self._h, 1, src.data_ptr(), dst.data_ptr(), C.c_void_p(stream)),
+                   "ffv2amd_upconvert_420_device")
+        return self.unpack_frames(dst.cpu().numpy())[0]
+
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
         r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,

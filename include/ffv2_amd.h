@@ -127,6 +127,21 @@ int  ffv2amd_encode_batch_to_host(ffv2amd_encoder *enc, int nframes, const void 
                                   uint8_t *h_packets, size_t packet_stride,
                                   uint32_t *h_sizes, int32_t *h_status);
 
+/* 4:2:0 front end.  encode2() takes 4:4:4 planar only, as the reference's
+ * does (ffv2enc.c:596-601, utils.c:814-822); handed yuv420p / yuv420p10le / yuv420p12le the
+ * reference TOOL converts first -- choose_pixel_fmt (fftools/ffmpeg_filter.c:63-131) picks
+ * yuv444p* of the same depth and an auto-inserted scale filter runs libswscale's default bicubic
+ * (libswscale/utils.c:332-727 initFilter; swscale.c:96-139; output.c:333-393): luma unchanged,
+ * chroma 2x up both ways.  These calls are that step on the GPU, for an encoder created with
+ * the yuv444p format of the same depth.  PARITY UNPINNED (no libswscale binary or vector here).
+ *   4:2:0 frames are tightly packed: Y (w x h), U, V (ceil(w/2) x ceil(h/2)), uint8 or uint16le,
+ *   ffv2amd_frame_bytes_420() bytes each. */
+size_t ffv2amd_frame_bytes_420(const ffv2amd_encoder *enc);
+int  ffv2amd_upconvert_420_device(ffv2amd_encoder *enc, int nframes, const void *d_src420,
+                                  void *d_frames444, void *stream);
+int  ffv2amd_encode_frame_420(ffv2amd_encoder *enc, const uint8_t *const data[3], const ptrdiff_t linesize[3],
+                              int qp, uint8_t *out, size_t out_cap, size_t *out_size);
+
 /* The same batch step for 1 <= qp <= 64 split in two, so that consecutive batches overlap:
  *   qp_submit : T-stage, PVQ search and symbol compaction of one batch, asynchronous on the
  *               encoder's stream (frames must be complete when it is called); at most two

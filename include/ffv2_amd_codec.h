@@ -64,6 +64,11 @@ int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:51
  * send order with the frame's pts.  flags: FFV2AMD_FRAME_PINNED of ffv2_amd.h.  qp == 0 only. */
 int  ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *frame, unsigned flags);
 int  ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt, int wait);
+/* The ffmpeg tool's format step + encode2 for yuv420p / yuv420p10le / yuv420p12le sources
+ * (fftools/ffmpeg_filter.c:63-131, auto-inserted bicubic scale filter): avctx initialised with the
+ * yuv444p* format of the same depth, frame->data[0..2] = Y, U, V.  Parity unpinned. */
+int  ffv2amd_codec_encode_yuv420(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
+                                 const FFV2AMDFrame *frame, int *got_packet_ptr);
 void ffv2amd_packet_unref(FFV2AMDPacket *pkt);
 
 #ifdef __cplusplus

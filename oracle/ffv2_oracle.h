@@ -86,6 +86,13 @@ int ffv2o_encode_frame(const uint8_t *const data[4], const ptrdiff_t linesize[4]
 /* PVQ search restating ff_pvq_search_exact_avx (celt_pvq_search.asm:214-368). */
 float ffv2o_pvq_search(float *X, int *y, int K, int N);
 
+/* ffv2_swscale_oracle.c: what the reference tool chain does to a 4:2:0 frame before encode2()
+ * (auto-inserted scale filter, flags=bicubic: libswscale/utils.c:332-727 initFilter,
+ * swscale.c:96-139, output.c:333-393).  PARITY UNPINNED. */
+int ffv2o_sws_chroma_filter(int n, int one, int16_t *filter_out, int32_t *pos_out, int cap_taps);
+int ffv2o_sws_420_to_444(const uint8_t *const src[3], const ptrdiff_t src_stride[3],
+                         uint8_t *const dst[3], const ptrdiff_t dst_stride[3], int w, int h, int depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,27 @@ class Oracle:
             ls[p] = frame[p].strides[0]
         return frame, data, ls
 
+    def sws_420_to_444(self, y, u, v, depth):
+        """Reference tool chain's 4:2:0 -> 4:4:4 (auto-inserted bicubic scale filter), oracle restatement."""
+        dt = np.uint8 if depth == 8 else np.dtype("<u2")
+        y = np.ascontiguousarray(y, dt); u = np.ascontiguousarray(u, dt); v = np.ascontiguousarray(v, dt)
+        h, w = y.shape
+        out = np.zeros((3, h, w), dt)
+        src = (C.c_void_p * 3)(y.ctypes.data, u.ctypes.data, v.ctypes.data)
+        ss = (C.c_ssize_t * 3)(y.strides[0], u.strides[0], v.strides[0])
+        dst = (C.c_void_p * 3)(out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data)
+        ds = (C.c_ssize_t * 3)(out[0].strides[0], out[1].strides[0], out[2].strides[0])
+        r = self.lib.ffv2o_sws_420_to_444(src, ss, dst, ds, C.c_int(w), C.c_int(h), C.c_int(depth))
+        assert r == 0, r
+        return out
+
+    def sws_chroma_filter(self, n, one):
+        f = np.zeros((n, 8), np.int16)
+        p = np.zeros(n, np.int32)
+        fs = self.lib.ffv2o_sws_chroma_filter(C.c_int(n), C.c_int(one), f.ctypes.data_as(C.c_void_p),
+                                              p.ctypes.data_as(C.c_void_p), C.c_int(8))
+        return f.reshape(-1)[: n * fs].reshape(n, fs).copy(), p
+
     def encode(self, frame, pix_fmt, qp=0, W=None):
         frame, data, ls = self._planes(frame)
         P, H, Wd = frame.shape

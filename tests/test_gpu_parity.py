@@ -394,9 +394,20 @@ def test_raw_frame_cli_reproduces_reference_md5(tmp_path):
     assert r.returncode == 0, r.stderr
     out = dst.read_bytes()
     assert (len(out), hashlib.md5(out).hexdigest()) == (9565, "08700eaee86fe100fef32f338264c357")
-    r = subprocess.run([os.path.join(root, "examples", "ffv2enc_cli"), "320", "240", "yuv420p", str(src), str(dst)],
-                       capture_output=True, text=True)
+    r = subprocess.run([os.path.join(root, "examples", "ffv2enc_cli"), "320", "240", "yuv420p", str(src), str(dst),
+                        "--no-convert"], capture_output=True, text=True)
     assert r.returncode == 2                                   # 4:2:0 is not an encoder input (ffv2enc.c:596-601)
+    # ... and with the tool's conversion step in front (yuv420p -> yuv444p, bicubic; parity unpinned)
+    from tests import oracle_lib
+    oracle = oracle_lib.load()
+    rng = np.random.default_rng(7)
+    y, u, v = (rng.integers(0, 256, s).astype(np.uint8) for s in ((240, 320), (120, 160), (120, 160)))
+    src420 = tmp_path / "in420.yuv"
+    src420.write_bytes(y.tobytes() + u.tobytes() + v.tobytes())
+    r = subprocess.run([os.path.join(root, "examples", "ffv2enc_cli"), "320", "240", "yuv420p", str(src420), str(dst)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert dst.read_bytes() == oracle.encode(oracle.sws_420_to_444(y, u, v, 8), "yuv444p")
 
 
 def test_avcodec_shaped_shim(oracle):

@@ -398,10 +398,15 @@ __device__ __forceinline__ void tstage_back_half(int (&x)[64], uint4 (&lut)[8], 
     }
     // coefficients last: 16 stores of 1 KiB per wave, nothing waits on them
     if (WRITE_COEF) {
-        int4 *cp = reinterpret_cast<int4 *>(a.coef + ((size_t)f * g.nblk + bp) * 4096);
+        // streamed past the caches (nontemporal): 16 KiB per block-plane written once and not read
+        // again by this kernel would otherwise push the neighbours' shared halo rows out of L2
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 *cp = reinterpret_cast<i32x4 *>(a.coef + ((size_t)f * g.nblk + bp) * 4096);
 #pragma unroll
-        for (int j = 0; j < 16; j++)
-            cp[j * 64 + lane] = make_int4(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]);
+        for (int j = 0; j < 16; j++) {
+            const i32x4 v = { x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3] };
+            __builtin_nontemporal_store(v, &cp[j * 64 + lane]);
+        }
     }
     // this block-plane's share of the frame's packet buffer, cleared for the E-stage's atomic ORs
     if (a.zero) {

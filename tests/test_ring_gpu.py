@@ -92,3 +92,26 @@ def test_ring_reports_a_bad_frame_and_moves_on(oracle):
     assert tag == 2 and pk == oracle.encode(good, fmt)
     enc.ring_close()
     enc.close()
+
+
+def test_qp_pipeline_two_batches_in_flight(oracle):
+    """ffv2amd_qp_submit / _finish: the GPU half of batch n+1 is issued before the host half of
+    batch n runs; a third submit is refused; packets equal the synchronous path and the oracle
+    (parity unpinned for qp > 0: the oracle restates the reference's PVQ asm)."""
+    W, H, fmt, P, depth, qp = 200, 130, "yuv444p", 3, 8, 16
+    from ffmpeg_ffv2_amd import FFV2Encoder, build
+    build.build()
+    enc = FFV2Encoder(W, H, fmt, device=0, max_batch=3)
+    batches = [np.stack([synth.noise(10 * b + n, P, H, W, depth) for n in range(3 - b)]) for b in range(3)]
+    dev = [enc.upload(b) for b in batches]
+    assert enc.qp_submit(dev[0], qp) and enc.qp_submit(dev[1], qp)
+    assert not enc.qp_submit(dev[2], qp)              # two in flight already: EAGAIN
+    got = [enc.qp_finish()]
+    assert enc.qp_submit(dev[2], qp)
+    got += [enc.qp_finish(), enc.qp_finish()]
+    for b in range(3):
+        assert len(got[b]) == 3 - b
+        for n in range(3 - b):
+            assert got[b][n] == oracle.encode(batches[b][n], fmt, qp=qp), (b, n)
+    assert got[0] == enc.encode_batch_to_host(dev[0], qp=qp)
+    enc.close()

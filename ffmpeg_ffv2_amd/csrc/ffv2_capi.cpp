@@ -415,6 +415,7 @@ struct ffv2amd_encoder {
     // per-batch workspace
     uint32_t *d_codes = nullptr, *d_bitoff = nullptr;
     int32_t  *d_status = nullptr;
+    int32_t  *d_err = nullptr;           // [2][max_batch] T-stage error flags of the (up to two) batch calls in flight
     // single-frame host path
     uint8_t  *d_frame = nullptr, *d_pkt = nullptr;
     uint32_t *d_meta = nullptr;          // [0] size, [1] status
@@ -508,15 +509,16 @@ static int encode_uploaded_frame(ffv2amd_encoder *e, int qp, const int32_t *W, u
 static int launch_encode_qp0(ffv2amd_encoder *e, int nframes, const void *d_frames, const int32_t *d_W,
                              void *d_packets, size_t packet_stride, uint32_t *d_sizes, int32_t *status,
                              uint32_t *codes, uint32_t *bitcnt, int32_t *coef, hipStream_t st, hipStream_t se,
-                             ffv2amd_encoder::EvTriple *ev)
+                             ffv2amd_encoder::EvTriple *ev, int32_t *err)
 {
-    HIPCHK(hipMemsetAsync(status, 0, sizeof(int32_t) * nframes, st));
-    // the packet buffers are cleared by the T-stage itself (FFV2TStageArgs::zero)
+    // No memset in front: `err` (zero between calls: cleared at allocation and by every E-stage)
+    // collects the T-stage's errors, the E-stage writes `status` from it.  The packet buffers are
+    // cleared by the T-stage itself (FFV2TStageArgs::zero).
     FFV2TStageArgs a{};
     a.g = e->geom; a.nframes = nframes; a.frames = (const uint8_t *)d_frames;
     a.coef = coef; a.energy = nullptr; a.codes = codes; a.bitcnt = bitcnt; a.W = d_W;
     a.gain_thr = e->d_thr; a.gain_n = GAIN_TABLE_N; a.lds_scan = e->d_lds_scan;
-    a.status = status;
+    a.status = err;
     a.zero = (uint32_t *)d_packets; a.zero_stride_dw = (uint32_t)(packet_stride / 4);
     if (ev) HIPCHK(hipEventRecord(ev->a, st));
     HIPCHK(ffv2_launch_tstage(a, st));
@@ -530,7 +532,7 @@ static int launch_encode_qp0(ffv2amd_encoder *e, int nframes, const void *d_fram
     FFV2EStageArgs b{};
     b.g = e->geom; b.nframes = nframes; b.codes = codes; b.bitoff = bitcnt;
     b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
-    b.sizes = d_sizes; b.status = status;
+    b.sizes = d_sizes; b.status = status; b.err = err;
     b.prefix = e->d_prefix; b.prefix_len = e->prefix_len; b.slack_bits = e->slack;
     // raw header: pix_fmt & 15 (daala_entropy.c:406), then Exp-Golomb(qp = 0) = "1"
     b.header_bits = ((uint32_t)e->info.pix_fmt & 15u) | (1u << 4);
@@ -579,7 +581,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     }
     if (e->q_copy) { (void)hipStreamSynchronize(e->q_copy); (void)hipStreamDestroy(e->q_copy); }
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
-    (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status);
+    (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status); (void)hipFree(e->d_err);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
     (void)hipFree(e->d_inv_plane);
     (void)hipFree(e->d_coef_ws); (void)hipFree(e->d_y); (void)hipFree(e->d_pk_ws); (void)hipFree(e->d_sizes_ws);
@@ -671,6 +673,8 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     CK(hipMalloc(&e->d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * g.nblk * (size_t)max_batch));
     CK(hipMalloc(&e->d_bitoff, sizeof(uint32_t) * g.nblk * (size_t)max_batch));
     CK(hipMalloc(&e->d_status, sizeof(int32_t) * (size_t)max_batch));
+    CK(hipMalloc(&e->d_err, sizeof(int32_t) * 2 * (size_t)max_batch));
+    CK(hipMemset(e->d_err, 0, sizeof(int32_t) * 2 * (size_t)max_batch));
     CK(hipMalloc(&e->d_frame, in.frame_stride));
     CK(hipMalloc(&e->d_pkt, in.packet_cap));
     CK(hipMalloc(&e->d_meta, 16));
@@ -750,7 +754,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     }
     e->seq_pb = pb;
     int r = launch_encode_qp0(e, nframes, d_frames, d_W, d_packets, packet_stride, d_sizes, status, codes, bitcnt,
-                              e->coef_sink, s, se, ev);
+                              e->coef_sink, s, se, ev, e->d_err + (size_t)pb * e->info.max_batch);
     if (r < 0) return r;
     if (pipe) {
         HIPCHK(hipEventRecord(e->evE[pb], se));
@@ -1262,6 +1266,7 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
         RK(hipMalloc(&r.d_frame, in.frame_stride));
         RK(hipMalloc(&r.d_pkt, in.packet_cap));
         RK(hipMalloc(&r.d_meta, 16));
+        RK(hipMemset(r.d_meta, 0, 16));                          // [2]: the T-stage's error flag, zero between calls
         RK(hipMalloc(&r.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb));
         RK(hipMalloc(&r.d_bitcnt, sizeof(uint32_t) * nb));
         RK(hipMalloc(&r.d_w, sizeof(int32_t) * nb));
@@ -1344,7 +1349,7 @@ int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const pt
     hipStream_t sc = e->ring_comp[e->ring_seq++ & 1u];
     HIPCHK(hipStreamWaitEvent(sc, r.ev_h2d, 0));
     int rc = launch_encode_qp0(e, 1, r.d_frame, dW, r.d_pkt, in.packet_cap, r.d_meta, (int32_t *)(r.d_meta + 1),
-                               r.d_codes, r.d_bitcnt, nullptr, sc, sc, nullptr);
+                               r.d_codes, r.d_bitcnt, nullptr, sc, sc, nullptr, (int32_t *)(r.d_meta + 2));
     if (rc < 0) return rc;
     HIPCHK(hipEventRecord(r.ev_done, sc));
     HIPCHK(hipStreamWaitEvent(e->ring_d2h, r.ev_done, 0));

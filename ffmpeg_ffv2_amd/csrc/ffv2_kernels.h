@@ -44,7 +44,8 @@ struct FFV2EStageArgs {
     uint8_t  *packets;                // [nframes][packet_stride], zeroed beforehand (FFV2TStageArgs::zero)
     size_t    packet_stride;
     uint32_t *sizes;                  // [nframes]
-    int32_t  *status;                 // [nframes]
+    int32_t  *status;                 // [nframes] written (not updated) by the E-stage
+    int32_t  *err;                    // [nframes] the T-stage's sticky error flags (its FFV2TStageArgs::status); read and cleared
     const uint8_t *prefix;            // range-coded prefix bytes (data independent at qp 0)
     int prefix_len, slack_bits;
     uint32_t header_bits, header_nbits; // raw bits in front of the first superblock

@@ -1120,7 +1120,12 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
     const bool fits = (size_t)total + 4 <= a.packet_stride;
     if (blockIdx.x == 0 && tid == 0) {
         a.sizes[f] = fits ? total : 0;
-        if (!fits) atomicMin(&a.status[f], -28);              // FFV2AMD_ERR_NOSPACE
+        // The frame's status word is WRITTEN here (no memset launch in front of the T-stage): the
+        // T-stage's sticky error flag, or NOSPACE; the flag is handed back cleared for the next call.
+        int32_t st = a.err[f];
+        a.err[f] = 0;
+        if (!fits && st > -28) st = -28;                      // FFV2AMD_ERR_NOSPACE
+        a.status[f] = st;
     }
     if (!fits) return;                                         // workgroup-uniform
 

@@ -32,6 +32,9 @@
 #include "ffv2_kernels.h"
 
 #include "gen/fdct64_net.h"
+#ifdef FFV2_ASM_NET        // experiment: python tools/gen_asm_net.py, then build with -DFFV2_ASM_NET
+#include "gen/fdct64_asm.h"
+#endif
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -287,9 +290,13 @@ __device__ __forceinline__ void tstage_back_half(int (&x)[64], uint4 (&lut)[8], 
         asm("" : "+v"(x[k]));
     }
     wave_lds_fence();                                         // tile is dead: LDS becomes int32 [64][65]
+#ifndef FFV2_ASM_NET
 #define FFV2_MULRS FFV2_MULRS_NOOVF
     FDCT64_NET(x);
 #undef FFV2_MULRS
+#else
+    FDCT64_ASM_COL(x);      // the same network as one asm block, constants streamed by s_load (tools/gen_asm_net.py)
+#endif
 #pragma unroll
     for (int v = 0; v < 64; v++) xb[lane * XPITCH + v] = x[OUTR[v]];      // tmp[64*col + v], ffv2.c:4957
     if (LOAD_LUT) {
@@ -305,9 +312,13 @@ __device__ __forceinline__ void tstage_back_half(int (&x)[64], uint4 (&lut)[8], 
 #pragma unroll
     for (int k = 0; k < 64; k++) x[k] = xb[k * XPITCH + lane];            // tmp + v, stride 64, ffv2.c:4959
     wave_lds_fence();
+#ifndef FFV2_ASM_NET
 #define FFV2_MULRS FFV2_MULRS_WRAP
     FDCT64_NET(x);
 #undef FFV2_MULRS
+#else
+    FDCT64_ASM_ROW(x);
+#endif
 #pragma unroll
     for (int u = 0; u < 64; u++) xb[lane * RPITCH + u] = x[OUTR[u]];      // dst[64*v + u]
     wave_lds_fence();

@@ -254,41 +254,51 @@ def main():
     # never as `value`.
     hb = None
     if not args.no_host_boundary:
-        from ffmpeg_ffv2_amd import fanout
-        nf = args.host_frames
-        hb = {}
-        variants = [("pinned", True)] + ([("pageable", False)] if world == 1 else [])
-        for name, pinned in variants:
-            dt, pk_local, frame_bytes = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
-                                                      pinned, barrier)
+        try:
+            from ffmpeg_ffv2_amd import fanout
+            nf = args.host_frames
+            hb = {}
+            variants = [("pinned", True)] + ([("pageable", False)] if world == 1 else [])
+            for name, pinned in variants:
+                dt, pk_local, frame_bytes = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
+                                                          pinned, barrier)
+                if world > 1:
+                    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt = float(tt.item())
+                hb[name] = {"Mpix_s": round(world * nf * W * H / dt / 1e6, 1), "ms_per_frame_per_gpu": round(dt / nf * 1e3, 4),
+                            "h2d_GBs_per_gpu": round(nf * frame_bytes / dt / 1e9, 2)}
+                if pinned:
+                    # in-order gather of every rank's packets on rank 0: frame n lives on rank n % world
+                    mine = fanout.local_frames(world * nf, rank, world)
+                    barrier()
+                    g0 = time.perf_counter()
+                    allp = fanout.gather_packets(pk_local, mine, world * nf, rank, world,
+                                                 device=dev if backend == "nccl" else None)
+                    barrier()
+                    hb["gather_ms"] = round((time.perf_counter() - g0) * 1e3, 3)
+                    if rank == 0:
+                        hb["ranks_seen"] = len({fanout.owner(n, world) for n, p in enumerate(allp) if p})
+                        hb["packets_gathered"] = sum(1 for p in allp if p)
+                        # frames cycle through the F benchmark frames: packet n of rank r == packet (n % F) of the device path
+                        hb["packets_match_device_path"] = bool(all(
+                            allp[n] == packets[(n // world) % F] for n in range(0, world * nf, world)))
+            rate = h2d_rate(dev, frame_bytes)
+            hb["h2d_copy_GBs"] = round(rate, 2)
+            hb["pinned_fraction_of_h2d_copy_rate"] = round(hb["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
+            hb["frames_per_gpu"] = nf
+            hb["ring_depth"] = args.ring_depth
+            hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "
+                          "H2D || T/E-stage || D2H on separate HIP streams; then in-order gather on rank 0")
+
+
+        except Exception as ex:          # never lose the headline line to the secondary phase
+            hb = {"error": "%s: %s" % (type(ex).__name__, ex)}
             if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
-            hb[name] = {"Mpix_s": round(world * nf * W * H / dt / 1e6, 1), "ms_per_frame_per_gpu": round(dt / nf * 1e3, 4),
-                        "h2d_GBs_per_gpu": round(nf * frame_bytes / dt / 1e9, 2)}
-            if pinned:
-                # in-order gather of every rank's packets on rank 0: frame n lives on rank n % world
-                mine = fanout.local_frames(world * nf, rank, world)
-                barrier()
-                g0 = time.perf_counter()
-                allp = fanout.gather_packets(pk_local, mine, world * nf, rank, world,
-                                             device=dev if backend == "nccl" else None)
-                barrier()
-                hb["gather_ms"] = round((time.perf_counter() - g0) * 1e3, 3)
-                if rank == 0:
-                    hb["ranks_seen"] = len({fanout.owner(n, world) for n, p in enumerate(allp) if p})
-                    hb["packets_gathered"] = sum(1 for p in allp if p)
-                    # frames cycle through the F benchmark frames: packet n of rank r == packet (n % F) of the device path
-                    hb["packets_match_device_path"] = bool(all(
-                        allp[n] == packets[(n // world) % F] for n in range(0, world * nf, world)))
-        rate = h2d_rate(dev, frame_bytes)
-        hb["h2d_copy_GBs"] = round(rate, 2)
-        hb["pinned_fraction_of_h2d_copy_rate"] = round(hb["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
-        hb["frames_per_gpu"] = nf
-        hb["ring_depth"] = args.ring_depth
-        hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "
-                      "H2D || T/E-stage || D2H on separate HIP streams; then in-order gather on rank 0")
+                try:
+                    dist.barrier()
+                except Exception:
+                    pass
 
     result = None
     if rank == 0:

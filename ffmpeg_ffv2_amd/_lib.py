@@ -10,7 +10,7 @@ EXPORTS = [
     "ffv2amd_version", "ffv2amd_encoder_create", "ffv2amd_encoder_destroy", "ffv2amd_encoder_info",
     "ffv2amd_encode_frame", "ffv2amd_encode_batch_device", "ffv2amd_tstage_device",
     "ffv2amd_coded_gain", "ffv2amd_range_prefix",
-    "ffv2amd_encoder_set_coef_sink", "ffv2amd_profile_enable", "ffv2amd_profile_read", "ffv2amd_tstage_kernel_name",
+    "ffv2amd_encoder_set_coef_sink", "ffv2amd_profile_enable", "ffv2amd_profile_read", "ffv2amd_tstage_kernel_name", "ffv2amd_debug_force_tstage",
     "ffv2amd_encoder_set_pipelined", "ffv2amd_encoder_flush", "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device", "ffv2amd_inverse_tstage_device",
     "ffv2amd_ring_open", "ffv2amd_ring_send", "ffv2amd_ring_receive", "ffv2amd_ring_pending", "ffv2amd_ring_close",
     "ffv2amd_host_alloc", "ffv2amd_host_free", "ffv2amd_qp_submit", "ffv2amd_qp_finish",
@@ -76,6 +76,8 @@ def load():
     lib.ffv2amd_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.ffv2amd_tstage_kernel_name.argtypes = [C.c_void_p, C.c_int]
     lib.ffv2amd_tstage_kernel_name.restype = C.c_char_p
+    lib.ffv2amd_debug_force_tstage.argtypes = [C.c_int]
+    lib.ffv2amd_debug_force_tstage.restype = None
     lib.ffv2amd_encoder_set_pipelined.argtypes = [C.c_void_p, C.c_int]
     lib.ffv2amd_encoder_flush.argtypes = [C.c_void_p, C.c_void_p]
     lib.ffv2amd_encode_batch_to_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -794,6 +794,8 @@ int ffv2amd_encoder_flush(ffv2amd_encoder *e, void *stream)
     return FFV2AMD_OK;
 }
 
+void ffv2amd_debug_force_tstage(int mode) { ffv2_tstage_force_variant(mode); }
+
 const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *e, int nframes)
 {
     if (!e || nframes < 1) return "";

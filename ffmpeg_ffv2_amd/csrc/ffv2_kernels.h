@@ -54,6 +54,7 @@ struct FFV2EStageArgs {
 #define FFV2_Y_STRIDE 4104        // int16 per block-plane of the PVQ output (4096 + phantom slot, padded)
 
 hipError_t ffv2_launch_tstage(const FFV2TStageArgs &a, hipStream_t s);
+void ffv2_tstage_force_variant(int mode);   // tests: 0 one-block kernel, 1 column-walking kernel, -1 automatic
 const char *ffv2_tstage_kernel_name(const FFV2Geom &g, int nframes, bool coef_writeback);   // which T-stage kernel a launch would use
 hipError_t ffv2_launch_inverse(const FFV2Geom &g, int nframes, const int32_t *coef, int32_t *plane,
                                uint8_t *frames, const uint16_t *lds_scan, hipStream_t s);

@@ -1223,9 +1223,14 @@ static int walk_slots(bool bps2, bool wc)
 
 // Column-walking kernel when every wavefront slot gets at least FFV2_WALK_MIN block-planes;
 // the one-block kernel otherwise (small pictures).  Returns the slot count, 0 = one-block kernel.
+static int g_tstage_force = -2;        // -2: not set (environment decides); else 0 block, 1 walk, -1 auto
+
+void ffv2_tstage_force_variant(int mode) { g_tstage_force = mode; }
+
 static int tstage_walk_slots(const FFV2Geom &g, int nframes, bool wc)
 {
-    static const int walk_mode = getenv("FFV2AMD_TSTAGE") ? atoi(getenv("FFV2AMD_TSTAGE")) : -1;   // 0 block, 1 walk, -1 auto
+    static const int env_mode = getenv("FFV2AMD_TSTAGE") ? atoi(getenv("FFV2AMD_TSTAGE")) : -1;   // 0 block, 1 walk, -1 auto
+    const int walk_mode = g_tstage_force != -2 ? g_tstage_force : env_mode;
     const uint64_t total64 = (uint64_t)g.nblk * (uint64_t)nframes;
     const int slots = walk_mode == 0 ? 0 : walk_slots(g.bytes_per_sample != 1, wc);
     if (slots > 0 && total64 < (1ull << 31) && (walk_mode == 1 || total64 >= (uint64_t)slots * FFV2_WALK_MIN)) return slots;

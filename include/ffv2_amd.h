@@ -213,6 +213,9 @@ int  ffv2amd_profile_enable(ffv2amd_encoder *enc, int on);
 /* Name of the T-stage kernel a *_batch_device call of `nframes` frames launches (two variants:
  * one 64x64 block-plane per wavefront, or wavefronts walking down columns of superblocks). */
 const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *enc, int nframes);
+/* Test hook (process-wide): 0 = always the one-block kernel, 1 = always the column-walking kernel,
+ * -1 = automatic (the default; the environment variable FFV2AMD_TSTAGE sets the same at start-up). */
+void ffv2amd_debug_force_tstage(int mode);
 int  ffv2amd_profile_read(ffv2amd_encoder *enc, double *tstage_ms, double *estage_ms, int *launches);
 
 /* Host helpers with no GPU work (unit-tested on CPU):

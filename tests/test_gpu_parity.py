@@ -536,3 +536,51 @@ def test_batch_encode_is_graph_capturable(oracle):
         torch.cuda.synchronize()
         assert enc.collect(*out) == [oracle.encode(fr2[n], fmt) for n in range(F)]
     enc.close()
+
+
+@pytest.fixture
+def force_tstage():
+    """Process-wide switch between the two T-stage kernels (automatic again afterwards)."""
+    from ffmpeg_ffv2_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    yield lib.ffv2amd_debug_force_tstage
+    lib.ffv2amd_debug_force_tstage(-1)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_both_tstage_kernels_on_odd_geometries(oracle, force_tstage, mode):
+    """The automatic choice sends small launches to the one-block kernel and large ones to the
+    column-walking kernel; here each is forced onto everything: ragged picture edges, single
+    superblock rows/columns, widths that cut a 16-byte vector, several frames per launch."""
+    force_tstage(mode)
+    rng = np.random.default_rng(100 + mode)
+    cases = [("gray", 1, 1, 1, 8), ("gray", 1, 17, 9, 8), ("yuv444p", 3, 65, 129, 8), ("yuv444p10le", 3, 130, 71, 10),
+             ("yuv444p12le", 3, 64, 64, 12), ("gbrp", 3, 200, 333, 8), ("gbrp10le", 3, 300, 70, 10),
+             ("yuv444p", 3, 700, 64, 8), ("yuv444p10le", 3, 63, 1000, 10)]
+    for fmt, P, H, W, depth in cases:
+        enc = _enc(W, H, fmt, max_batch=3)
+        assert enc.tstage_kernel_name(3) == ("ffv2_tstage_walk_kernel" if mode else "ffv2_tstage_kernel")
+        frames = np.stack([synth.make("S2" if n else "S1", int(rng.integers(1 << 20)), P, H, W, depth) for n in range(3)])
+        coef, en = enc.tstage(enc.upload(frames))
+        coef, en = coef.cpu().numpy(), en.cpu().numpy()
+        got = enc.collect(*enc.encode_batch_device(enc.upload(frames)))
+        for n in range(3):
+            coef_o, en_o = oracle.tstage(frames[n], fmt)
+            assert np.array_equal(coef[n], coef_o) and np.array_equal(en[n], en_o), (fmt, H, W, n)
+            assert got[n] == oracle.encode(frames[n], fmt), (fmt, H, W, n)
+        enc.close()
+
+
+def test_walk_kernel_sample_out_of_range_and_full_frames(oracle, force_tstage):
+    force_tstage(1)
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    enc = _enc(192, 128, "yuv444p10le")
+    bad = synth.make("S1", 0, 3, 128, 192, 10)
+    bad[2, 100, 3] = 1 << 10
+    with pytest.raises(FFV2Error) as ei:
+        enc.encode2(bad)
+    assert ei.value.code == -34
+    good = synth.make("S2", 1, 3, 128, 192, 10)
+    assert enc.encode2(good) == oracle.encode(good, "yuv444p10le")      # the error flag does not stick
+    enc.close()

@@ -431,7 +431,8 @@ struct ffv2amd_encoder {
     uint32_t *d_sizes_ws = nullptr;
     // options
     int32_t *coef_sink = nullptr;
-    bool profiling = false;
+    int profiling = 0;                   // 0 off, n: HIP timing events around every n-th batch call
+    unsigned prof_calls = 0;
     struct EvTriple { hipEvent_t a, b, c, d; };     // T start, T end, E end, E start
     // pipelined mode: the E-stage of call n runs on e_stream while the caller's stream
     // already carries the T-stage of call n+1; two sets of T->E hand-off buffers
@@ -737,7 +738,7 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (pipe && e->evE_valid[pb])                  // the E-stage two calls ago read this hand-off buffer
         HIPCHK(hipStreamWaitEvent(s, e->evE[pb], 0));
     ffv2amd_encoder::EvTriple *ev = nullptr;
-    if (e->profiling) {
+    if (e->profiling > 0 && (e->prof_calls++ % (unsigned)e->profiling) == 0) {
         if (e->ev_used == e->ev_pool.size()) {
             if (e->ev_pool.size() >= 8192) {                 // drain before growing without bound
                 double t, x; int n;
@@ -814,7 +815,8 @@ int ffv2amd_encoder_set_coef_sink(ffv2amd_encoder *e, int32_t *d_coef)
 int ffv2amd_profile_enable(ffv2amd_encoder *e, int on)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
-    e->profiling = on != 0;
+    e->profiling = on < 0 ? 0 : on;
+    e->prof_calls = 0;
     return FFV2AMD_OK;
 }
 

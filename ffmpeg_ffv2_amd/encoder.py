@@ -323,7 +323,8 @@ class FFV2Encoder:
         self._pinned = []
 
     def profile(self, on=True):
-        _lib.check(self._lib.ffv2amd_profile_enable(self._h, 1 if on else 0), "profile_enable")
+        """on: False/0 off, True/1 every call, n > 1 every n-th call (HIP timing events around the two kernels)."""
+        _lib.check(self._lib.ffv2amd_profile_enable(self._h, int(on)), "profile_enable")
 
     def tstage_kernel_name(self, nframes):
         return self._lib.ffv2amd_tstage_kernel_name(self._h, int(nframes)).decode()

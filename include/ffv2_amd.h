@@ -209,7 +209,8 @@ void  ffv2amd_host_free(void *p);
  * T-stage kernel and around the E-stage kernels of every *_batch_device call.
  * profile_read waits for the recorded events, returns the summed durations (ms)
  * and the number of batch launches since the last read, and resets the counters. */
-int  ffv2amd_profile_enable(ffv2amd_encoder *enc, int on);
+int  ffv2amd_profile_enable(ffv2amd_encoder *enc, int on);   /* on = n > 1: only every n-th call is timed (the timing
+                                                                 events themselves cost ~3 % of a 0.37 ms step) */
 /* Name of the T-stage kernel a *_batch_device call of `nframes` frames launches (two variants:
  * one 64x64 block-plane per wavefront, or wavefronts walking down columns of superblocks). */
 const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *enc, int nframes);

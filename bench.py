@@ -103,6 +103,8 @@ def main():
                     help="E-stage of step n on the encoder's own stream, overlapping the T-stage of step n+1 "
                          "(measured: ~1 % more Mpix/s, but the T-stage timing then includes the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--device-coder", action="store_true",
+                    help="with --qp: the adaptive range coder on the device (one wavefront per frame) instead of host threads")
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed clock-settling pre-roll")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-frames-in / host-packets-out phase")
     ap.add_argument("--host-frames", type=int, default=48, help="frames per rank in the host-boundary phase")
@@ -160,6 +162,7 @@ def main():
         # T-stage + PVQ search + symbol compaction on the GPU, adaptive range coder on host threads
         # (one serial chain per frame, ffv2enc.c:461), batch n+1 on the GPU while batch n is coded.
         # PARITY UNPINNED for qp > 0: the oracle restates the reference's PVQ asm, nothing pins it.
+        enc.set_device_coder(args.device_coder)
         for _ in range(max(args.warmup, 1)):
             enc.qp_submit(d_frames, args.qp)
             pk = enc.qp_finish()
@@ -184,7 +187,8 @@ def main():
                    "vs_baseline": None, "dtype": "int32 + f32 (PVQ search)", "data": "synthetic",
                    "config": {"workload": "%dx%d %s qp=%d, %d frames per step per GPU, frames resident in HBM, "
                                           "packets to host memory" % (W, H, fmt, args.qp, F),
-                              "packet_bytes_frame0": len(pk[0]), "host_threads": min(F, os.cpu_count() or 1)},
+                              "packet_bytes_frame0": len(pk[0]), "host_threads": min(F, os.cpu_count() or 1),
+                              "range_coder": "device, one wavefront per frame" if args.device_coder else "host threads"},
                    "roofline": None}
             if world == 1 and not args.no_cpu_baseline:
                 from tests import oracle_lib

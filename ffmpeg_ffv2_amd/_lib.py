@@ -13,7 +13,7 @@ EXPORTS = [
     "ffv2amd_encoder_set_coef_sink", "ffv2amd_profile_enable", "ffv2amd_profile_read", "ffv2amd_tstage_kernel_name", "ffv2amd_debug_force_tstage",
     "ffv2amd_encoder_set_pipelined", "ffv2amd_encoder_flush", "ffv2amd_encode_batch_to_host", "ffv2amd_pvq_search_device", "ffv2amd_inverse_tstage_device",
     "ffv2amd_ring_open", "ffv2amd_ring_send", "ffv2amd_ring_receive", "ffv2amd_ring_pending", "ffv2amd_ring_close",
-    "ffv2amd_host_alloc", "ffv2amd_host_free", "ffv2amd_qp_submit", "ffv2amd_qp_finish",
+    "ffv2amd_host_alloc", "ffv2amd_host_free", "ffv2amd_qp_submit", "ffv2amd_qp_finish", "ffv2amd_encoder_set_device_coder",
     "ffv2amd_frame_bytes_420", "ffv2amd_upconvert_420_device", "ffv2amd_encode_frame_420",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
@@ -97,6 +97,7 @@ def load():
     lib.ffv2amd_host_alloc.restype = C.c_void_p
     lib.ffv2amd_host_free.argtypes = [C.c_void_p]
     lib.ffv2amd_host_free.restype = None
+    lib.ffv2amd_encoder_set_device_coder.argtypes = [C.c_void_p, C.c_int]
     lib.ffv2amd_qp_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ffv2amd_qp_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.ffv2amd_frame_bytes_420.argtypes = [C.c_void_p]

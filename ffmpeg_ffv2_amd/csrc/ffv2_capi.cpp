@@ -460,7 +460,14 @@ struct ffv2amd_encoder {
         std::vector<hipEvent_t> ev_frame;
         int nframes = 0, qp = 0;
         bool busy = false;
+        // device coder (ffv2amd_encoder_set_device_coder): scratch and packets in HBM
+        uint16_t *d_pre = nullptr;
+        uint8_t *d_raw = nullptr, *d_pk = nullptr;
+        uint32_t *d_pk_sizes = nullptr, *h_pk_sizes = nullptr;
+        int32_t *d_pk_status = nullptr, *h_pk_status = nullptr;
+        bool on_device = false;          // this batch was coded by the device coder
     };
+    bool device_coder = false;
     QpSet qset[2];
     size_t q_stream_stride = 0;
     hipStream_t q_copy = nullptr;
@@ -579,6 +586,9 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
         if (q.h_status) (void)hipHostFree(q.h_status);
         if (q.ev) (void)hipEventDestroy(q.ev);
         for (auto ev : q.ev_frame) (void)hipEventDestroy(ev);
+        (void)hipFree(q.d_pre); (void)hipFree(q.d_raw); (void)hipFree(q.d_pk); (void)hipFree(q.d_pk_sizes); (void)hipFree(q.d_pk_status);
+        if (q.h_pk_sizes) (void)hipHostFree(q.h_pk_sizes);
+        if (q.h_pk_status) (void)hipHostFree(q.h_pk_status);
     }
     if (e->q_copy) { (void)hipStreamSynchronize(e->q_copy); (void)hipStreamDestroy(e->q_copy); }
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
@@ -1051,6 +1061,14 @@ static int qp_alloc(ffv2amd_encoder *e)
     return FFV2AMD_OK;
 }
 
+int ffv2amd_encoder_set_device_coder(ffv2amd_encoder *e, int on)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    if (e->q_fin != e->q_sub) return FFV2AMD_ERR_INVAL;          // not while batches are in flight
+    e->device_coder = on != 0;
+    return FFV2AMD_OK;
+}
+
 int ffv2amd_qp_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W)
 {
     if (!e || !d_frames || nframes < 1 || nframes > e->info.max_batch) return FFV2AMD_ERR_INVAL;
@@ -1073,6 +1091,32 @@ int ffv2amd_qp_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int
     HIPCHK(ffv2_launch_tstage(a, s));
     HIPCHK(ffv2_launch_pvq(e->d_coef_ws, d_W, e->d_y, qp, (long long)nb * nframes, s));
     HIPCHK(ffv2_launch_compact(e->d_y, qp, (int)nb, nframes, q.d_rec, q.d_stream, e->q_stream_stride, q.d_totals, s));
+    q.on_device = e->device_coder;
+    if (q.on_device) {
+        // the whole entropy coder on the device: one wavefront per frame (ffv2_rangecoder.hip)
+        const size_t cap = in.packet_cap_qp, B = (size_t)in.max_batch;
+        if (!q.d_pre) {
+            HIPCHK(hipMalloc(&q.d_pre, sizeof(uint16_t) * cap * B));
+            HIPCHK(hipMalloc(&q.d_raw, cap * B));
+            HIPCHK(hipMalloc(&q.d_pk, cap * B));
+            HIPCHK(hipMalloc(&q.d_pk_sizes, sizeof(uint32_t) * B));
+            HIPCHK(hipMalloc(&q.d_pk_status, sizeof(int32_t) * B));
+            HIPCHK(hipHostMalloc(&q.h_pk_sizes, sizeof(uint32_t) * B, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc(&q.h_pk_status, sizeof(int32_t) * B, hipHostMallocDefault));
+        }
+        FFV2RangeCoderArgs rc{};
+        rc.codes = q.d_codes; rc.rec = q.d_rec; rc.stream = q.d_stream; rc.stream_stride = e->q_stream_stride;
+        rc.status_in = q.d_status; rc.pre = q.d_pre; rc.raw = q.d_raw; rc.cap = cap;
+        rc.packets = q.d_pk; rc.packet_stride = cap; rc.sizes = q.d_pk_sizes; rc.status = q.d_pk_status;
+        rc.nblk = (int)nb; rc.nsb = in.num_sb_x * in.num_sb_y; rc.planes = in.planes; rc.pix_fmt = in.pix_fmt; rc.qp = qp;
+        HIPCHK(ffv2_launch_rangecoder(rc, nframes, s));
+        HIPCHK(hipMemcpyAsync(q.h_pk_sizes, q.d_pk_sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(q.h_pk_status, q.d_pk_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(q.ev, s));
+        q.nframes = nframes; q.qp = qp; q.busy = true;
+        e->q_sub++;
+        return FFV2AMD_OK;
+    }
     HIPCHK(hipMemcpyAsync(q.h_totals, q.d_totals, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(q.h_status, q.d_status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(q.h_rec, q.d_rec, sizeof(FFV2SymRec) * nb * nframes, hipMemcpyDeviceToHost, s));
@@ -1094,6 +1138,22 @@ int ffv2amd_qp_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t packet_stri
     const size_t nb = (size_t)in.block_planes;
     const int nframes = q.nframes, qp = q.qp;
     HIPCHK(hipEventSynchronize(q.ev));
+    if (q.on_device) {
+        // packets were finished on the device: bring each one back with its own size
+        for (int f = 0; f < nframes; f++) {
+            h_status[f] = q.h_pk_status[f];
+            h_sizes[f] = 0;
+            if (h_status[f] < 0) continue;
+            if (q.h_pk_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
+            h_sizes[f] = q.h_pk_sizes[f];
+            HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, q.d_pk + (size_t)f * in.packet_cap_qp, q.h_pk_sizes[f],
+                                  hipMemcpyDeviceToHost, e->q_copy));
+        }
+        HIPCHK(hipStreamSynchronize(e->q_copy));
+        q.busy = false;
+        e->q_fin++;
+        return FFV2AMD_OK;
+    }
     // each frame's symbol stream: its own size, on the copy stream, one event per frame
     for (int f = 0; f < nframes; f++) {
         h_status[f] = q.h_status[f];

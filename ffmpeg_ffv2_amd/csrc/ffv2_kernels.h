@@ -78,3 +78,21 @@ void ffv2_upconv_destroy(FFV2Upconv *u);
 size_t ffv2_upconv_src_frame_bytes(int w, int h, int depth);
 hipError_t ffv2_launch_upconv(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src,
                               size_t src_frame_stride, uint8_t *dst, hipStream_t s);
+
+// qp > 0 entropy coder on the device (ffv2_rangecoder.hip): one wavefront per frame
+struct FFV2RangeCoderArgs {
+    const uint32_t *codes;            // [nframes][nblk][16] T-stage records
+    const FFV2SymRec *rec;            // [nframes][nblk]
+    const int8_t *stream;             // [nframes][stream_stride] compact pulses
+    size_t stream_stride;
+    const int32_t *status_in;         // [nframes] T-stage status (a failed frame is skipped)
+    uint16_t *pre;                    // [nframes][cap] scratch: pre-carry range words
+    uint8_t *raw;                     // [nframes][cap] scratch: raw bytes in write order
+    size_t cap;
+    uint8_t *packets;                 // [nframes][packet_stride]
+    size_t packet_stride;
+    uint32_t *sizes;                  // [nframes]
+    int32_t *status;                  // [nframes]
+    int nblk, nsb, planes, pix_fmt, qp;
+};
+hipError_t ffv2_launch_rangecoder(const FFV2RangeCoderArgs &a, int nframes, hipStream_t s);

@@ -174,6 +174,10 @@ class FFV2Encoder:
                    "ffv2amd_upconvert_420_device")
         return self.unpack_frames(dst.cpu().numpy())[0]
 
+    def set_device_coder(self, on=True):
+        """qp > 0: run the adaptive range coder on the device (one wavefront per frame) instead of host threads."""
+        _lib.check(self._lib.ffv2amd_encoder_set_device_coder(self._h, 1 if on else 0), "set_device_coder")
+
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
         r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,

@@ -149,6 +149,12 @@ int  ffv2amd_encode_frame_420(ffv2amd_encoder *enc, const uint8_t *const data[3]
  *   qp_finish : oldest submitted batch -> packets in host memory; runs the range coder on host
  *               threads, one frame per thread.  FFV2AMD_ERR_AGAIN when nothing is submitted.
  * submit(n+1) issued before finish(n) hides the GPU work behind the host coder. */
+/* Where the adaptive range coder of qp > 0 runs.  0 (default): on host threads, one frame per
+ * thread, behind the GPU.  1: on the device, one wavefront per frame (ffv2_rangecoder.hip: the
+ * serial symbol loop on one lane, the carry propagation of encode_done as a wavefront prefix
+ * scan) -- the north_star's device coder; several times slower per frame than a host core, because
+ * the coder is one dependent chain per frame, but nothing crosses PCIe except the finished packets. */
+int  ffv2amd_encoder_set_device_coder(ffv2amd_encoder *enc, int on);
 int  ffv2amd_qp_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                        uint32_t *h_sizes, int32_t *h_status);

@@ -115,3 +115,42 @@ def test_qp_pipeline_two_batches_in_flight(oracle):
             assert got[b][n] == oracle.encode(batches[b][n], fmt, qp=qp), (b, n)
     assert got[0] == enc.encode_batch_to_host(dev[0], qp=qp)
     enc.close()
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", [("gray", 1, 64, 64, 8), ("yuv444p", 3, 100, 150, 8), ("yuv444p10le", 3, 130, 200, 10)])
+@pytest.mark.parametrize("qp", [4, 16, 64])
+def test_device_range_coder_matches_host_coder_and_oracle(oracle, fmt, P, H, W, depth, qp):
+    """SURVEY.md 8/A14 on the device: ffv2_rangecoder.hip (serial symbol loop on one lane per frame,
+    carry propagation as a wavefront prefix scan) against the host coder and the oracle.
+    Parity unpinned for qp > 0 (the oracle restates the reference's PVQ asm)."""
+    from ffmpeg_ffv2_amd import FFV2Encoder, build
+    build.build()
+    enc = FFV2Encoder(W, H, fmt, device=0, max_batch=3)
+    frames = np.stack([synth.noise(7 * qp + n, P, H, W, depth) for n in range(3)])
+    dev = enc.upload(frames)
+    host = enc.encode_batch_to_host(dev, qp=qp)
+    enc.set_device_coder(True)
+    got = enc.encode_batch_to_host(dev, qp=qp)
+    enc.set_device_coder(False)
+    for n in range(3):
+        assert got[n] == host[n] == oracle.encode(frames[n], fmt, qp=qp), n
+    enc.close()
+
+
+def test_device_range_coder_abort_conditions(oracle):
+    """Where the reference would av_assert0 (daala_entropy.c:336: all pulses of a band on one
+    coefficient; qp = 1) the device coder reports FFV2AMD_ERR_ABORT like the host coder."""
+    from ffmpeg_ffv2_amd import FFV2Encoder
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    enc = FFV2Encoder(64, 64, "gray", device=0, max_batch=1)
+    enc.set_device_coder(True)
+    flat = np.full((1, 1, 64, 64), 200, np.uint8)
+    flat[0, 0, 10, 10] = 0                         # a single impulse: structured content concentrates pulses
+    with pytest.raises(FFV2Error) as ei:
+        enc.encode_batch_to_host(enc.upload(flat), qp=16)
+    host_code = ei.value.code
+    enc.set_device_coder(False)
+    with pytest.raises(FFV2Error) as ei2:
+        enc.encode_batch_to_host(enc.upload(flat), qp=16)
+    assert host_code == ei2.value.code == -1
+    enc.close()

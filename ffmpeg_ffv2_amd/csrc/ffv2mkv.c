@@ -20,6 +20,10 @@
 #define ID_DOCTYPEVERSION  0x4287u
 #define ID_DOCTYPEREADVER  0x4285u
 #define ID_SEGMENT         0x18538067u
+#define ID_SEEKHEAD        0x114D9B74u
+#define ID_SEEKENTRY       0x4DBBu
+#define ID_SEEKID          0x53ABu
+#define ID_SEEKPOSITION    0x53ACu
 #define ID_INFO            0x1549A966u
 #define ID_TIMECODESCALE   0x2AD7B1u
 #define ID_MUXINGAPP       0x4D80u
@@ -187,15 +191,14 @@ int ffv2amd_mkv_open(ffv2amd_mkv **out, const char *path, int width, int height,
     r |= put_size8(&file, 0);
     m->segment_data_pos = (long)file.n;
     /* Info, matroskaenc.c:1896-1946: TimecodeScale 1 ms, app strings, Duration as a double */
+    Buf info = { 0 }, tracks = { 0 }, seek = { 0 }, one = { 0 };
     b.n = 0;
     r |= put_uint(&b, ID_TIMECODESCALE, 1000000);
     r |= put_str(&b, ID_MUXINGAPP, "ffv2_amd");
     r |= put_str(&b, ID_WRITINGAPP, "ffv2_amd");
     const size_t dur_in_info = b.n;
     r |= put_f64(&b, ID_DURATION, 0.0);
-    const size_t info_at = file.n;
-    r |= put_master(&file, ID_INFO, &b);
-    m->duration_pos = (long)(info_at + id_bytes(ID_INFO) + 1 + dur_in_info + id_bytes(ID_DURATION) + 1);
+    r |= put_master(&info, ID_INFO, &b);
     /* Tracks, matroskaenc.c:1192-1374: one video TrackEntry */
     r |= put_uint(&v, ID_PIXELWIDTH, (uint64_t)width);
     r |= put_uint(&v, ID_PIXELHEIGHT, (uint64_t)height);
@@ -210,11 +213,37 @@ int ffv2amd_mkv_open(ffv2amd_mkv **out, const char *path, int width, int height,
     r |= put_master(&t, ID_VIDEO, &v);
     b.n = 0;
     r |= put_master(&b, ID_TRACKENTRY, &t);
-    r |= put_master(&file, ID_TRACKS, &b);
-    if (r) r = -ENOMEM;
+    r |= put_master(&tracks, ID_TRACKS, &b);
+    /* SeekHead in front (matroskaenc.c:1881-1894 mkv_start_seekhead / :520-560 mkv_write_seekhead): where
+     * Info and Tracks start, relative to the first byte of the segment's data.  Both follow the
+     * SeekHead directly, so its own size is part of the positions: 4-byte positions keep it fixed.
+     * (The stock muxer also reserves a Void behind it and, for tracks with key frames, adds Cues at
+     * the end; FFV2 packets carry no key-frame flag, ffv2enc.c never sets AV_PKT_FLAG_KEY, so a stock
+     * file has no Cues either.) */
+    {
+        const uint32_t ids[2] = { ID_INFO, ID_TRACKS };
+        const size_t entry = id_bytes(ID_SEEKENTRY) + 1 + (id_bytes(ID_SEEKID) + 1 + 4) + (id_bytes(ID_SEEKPOSITION) + 1 + 4);
+        const size_t seekhead_size = id_bytes(ID_SEEKHEAD) + 1 + 2 * entry;
+        const size_t pos[2] = { seekhead_size, seekhead_size + info.n };
+        for (int i = 0; i < 2; i++) {
+            const uint8_t idb[4] = { (uint8_t)(ids[i] >> 24), (uint8_t)(ids[i] >> 16), (uint8_t)(ids[i] >> 8), (uint8_t)ids[i] };
+            const uint8_t pb[4] = { (uint8_t)(pos[i] >> 24), (uint8_t)(pos[i] >> 16), (uint8_t)(pos[i] >> 8), (uint8_t)pos[i] };
+            one.n = 0;
+            r |= put_id(&one, ID_SEEKID);       r |= put_size(&one, 4); r |= buf_put(&one, idb, 4);
+            r |= put_id(&one, ID_SEEKPOSITION); r |= put_size(&one, 4); r |= buf_put(&one, pb, 4);
+            r |= put_master(&seek, ID_SEEKENTRY, &one);
+        }
+        r |= put_master(&file, ID_SEEKHEAD, &seek);
+        if (!r && file.n - (size_t)m->segment_data_pos != seekhead_size) r = -EINVAL;
+    }
+    const size_t info_at = file.n;
+    r |= buf_put(&file, info.p, info.n);
+    m->duration_pos = (long)(info_at + id_bytes(ID_INFO) + 1 + dur_in_info + id_bytes(ID_DURATION) + 1);
+    r |= buf_put(&file, tracks.p, tracks.n);
+    if (r > 0) r = -ENOMEM;
     if (!r && info_at + id_bytes(ID_INFO) + 1 >= file.n) r = -EINVAL;
     if (!r && fwrite(file.p, 1, file.n, m->f) != file.n) r = -EIO;
-    free(file.p); free(b.p); free(t.p); free(v.p);
+    free(file.p); free(b.p); free(t.p); free(v.p); free(info.p); free(tracks.p); free(seek.p); free(one.p);
     if (r) { fclose(m->f); free(m); return r; }
     *out = m;
     return 0;

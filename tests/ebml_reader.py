@@ -3,14 +3,14 @@ Matroska element table for the handful of ids the muxer may emit).  Not the writ
 import struct
 
 MASTERS = {0x1A45DFA3: "EBML", 0x18538067: "Segment", 0x1549A966: "Info", 0x1654AE6B: "Tracks", 0xAE: "TrackEntry",
-           0xE0: "Video", 0x1F43B675: "Cluster"}
+           0xE0: "Video", 0x1F43B675: "Cluster", 0x114D9B74: "SeekHead", 0x4DBB: "Seek"}
 UINTS = {0x4286: "EBMLVersion", 0x42F7: "EBMLReadVersion", 0x42F2: "EBMLMaxIDLength", 0x42F3: "EBMLMaxSizeLength",
          0x4287: "DocTypeVersion", 0x4285: "DocTypeReadVersion", 0x2AD7B1: "TimecodeScale", 0xD7: "TrackNumber",
          0x73C5: "TrackUID", 0x9C: "FlagLacing", 0x83: "TrackType", 0x23E383: "DefaultDuration", 0xB0: "PixelWidth",
-         0xBA: "PixelHeight", 0x54B2: "DisplayUnit", 0xE7: "Timecode"}
+         0xBA: "PixelHeight", 0x54B2: "DisplayUnit", 0xE7: "Timecode", 0x53AC: "SeekPosition"}
 STRINGS = {0x4282: "DocType", 0x4D80: "MuxingApp", 0x5741: "WritingApp", 0x22B59C: "Language", 0x86: "CodecID"}
 FLOATS = {0x4489: "Duration"}
-BINARY = {0xA3: "SimpleBlock", 0x63A2: "CodecPrivate", 0xEC: "Void"}
+BINARY = {0xA3: "SimpleBlock", 0x63A2: "CodecPrivate", 0xEC: "Void", 0x53AB: "SeekID"}
 
 
 def read_id(b, p):

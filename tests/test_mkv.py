@@ -40,7 +40,15 @@ def test_header_tracks_and_payloads(tmp_path):
     assert ebml == {"EBMLVersion": 1, "EBMLReadVersion": 1, "EBMLMaxIDLength": 4, "EBMLMaxSizeLength": 8,
                     "DocType": "matroska", "DocTypeVersion": 4, "DocTypeReadVersion": 2}
     seg = tree[1][1]
-    assert [n for n, _ in seg][:2] == ["Info", "Tracks"]
+    assert [n for n, _ in seg][:3] == ["SeekHead", "Info", "Tracks"]
+    # the SeekHead's positions (relative to the segment's first data byte) land on the elements they name
+    seg_id0 = data.index(bytes.fromhex("18538067"))
+    _, seg_data = E.read_size(data, seg_id0 + 4)
+    seeks = [dict(s) for n, s in E.child(seg, "SeekHead") if n == "Seek"]
+    assert [s["SeekID"].hex() for s in seeks] == ["1549a966", "1654ae6b"]
+    for s in seeks:
+        at = seg_data + s["SeekPosition"]
+        assert data[at:at + 4] == s["SeekID"]
     info = dict(E.child(seg, "Info"))
     assert info["TimecodeScale"] == 1000000
     assert info["Duration"] == 200.0                       # 5 frames at 25 fps, in ms

@@ -5,7 +5,7 @@ libs=sys.argv[1:]
 keep=SO+".keep"; shutil.copy(SO,keep)
 res={l:[] for l in libs}
 try:
-    for _ in range(2):
+    for _ in range(int(os.environ.get("AB_ROUNDS","2"))):
         for lib in libs:
             shutil.copy(lib,SO)
             out=subprocess.run([sys.executable,"bench.py","--no-cpu-baseline","--no-host-boundary","--steps","100"],capture_output=True,text=True,check=True).stdout

@@ -1074,15 +1074,6 @@ __device__ __forceinline__ void put_golomb(LdsBitSink &s, uint32_t val)
     }
 }
 
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *scratch, int tid)
-{
-    v = (uint32_t)__builtin_amdgcn_readlane(wave_iscan((int)v), 63);
-    __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
-    __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
-}
-
 // E-stage at qp == 0, one launch: workgroup (b, f) owns block-planes [256b, 256b+256)
 // of frame f.  It (1) sums the raw-bit counts of the whole frame (24 KB, L2) to get
 // its own starting bit and the packet size -- the "prefix sum" is recomputed per
@@ -1101,14 +1092,22 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
 
     // (1) bits in front of this workgroup, and in the whole frame; every superblock is
     // preceded by its 4 transform-type bits (ffv2enc.c:197)
+    // (the 4 bits per superblock are counted in closed form: ceil(i0/P) superblocks start in front
+    // of this workgroup, n/P in the frame; the two sums share one pair of barriers)
     uint32_t before = 0, all = 0;
     for (int i = tid; i < n; i += EP_THREADS) {
-        const uint32_t v = cnt[i] + ((i % P) == 0 ? 4u : 0u);
+        const uint32_t v = cnt[i];
         all += v;
         before += i < i0 ? v : 0u;
     }
-    before = block_sum(before, scratch, tid);
-    all = block_sum(all, scratch + 4, tid);
+    {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane(wave_iscan((int)before), 63);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane(wave_iscan((int)all), 63);
+        if ((tid & 63) == 0) { scratch[tid >> 6] = b; scratch[4 + (tid >> 6)] = t; }
+        __syncthreads();
+        before = scratch[0] + scratch[1] + scratch[2] + scratch[3] + 4u * (uint32_t)((i0 + P - 1) / P);
+        all = scratch[4] + scratch[5] + scratch[6] + scratch[7] + 4u * (uint32_t)(n / P);
+    }
 
     const int i = i0 + tid;
     const bool have = i < n;

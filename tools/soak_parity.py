@@ -50,6 +50,7 @@ while time.time() - t0 < budget:
     if rng.random() < 0.15 and W * H < 200000:
         qp = int(rng.choice([4, 16, 64]))
         noise = np.stack([synth.noise(int(rng.integers(1 << 20)), P, H, W, depth) for _ in range(F)])
+        enc.set_device_coder(bool(rng.random() < 0.3) and W * H < 40000)     # sometimes the device range coder
         try:
             pk = enc.encode_batch_to_host(enc.upload(noise), qp=qp)
             for k in range(F):
@@ -73,5 +74,7 @@ while time.time() - t0 < budget:
         n420 += 1
     enc.close()
     n += 1
+    if n % 500 == 0:
+        print("  ... %d geometries, %.0f s" % (n, time.time() - t0), flush=True)
 lib.ffv2amd_debug_force_tstage(-1)
 print("soak ok: %d geometries (%d with qp > 0, %d with 4:2:0) in %.0f s" % (n, nq, n420, time.time() - t0))

@@ -23,10 +23,7 @@ namespace {
 constexpr int PVQ_MAXN4 = 2052;               // band 12: 2049 coefficients -> 513 4-vectors
 
 struct PvqLds {
-    float ax[PVQ_MAXN4];                      // |x|, for broadcast reads of the chosen element
-    float fy[PVQ_MAXN4];                      // running pulse vector
-    float s1[PVQ_MAXN4];                      // staging for the sequential sums
-    float s2[PVQ_MAXN4];
+    float s[PVQ_MAXN4];                       // staging for the sequential sums (8 KB -> 4 wavefronts per SIMD)
 };
 
 // sum of class `cls` from the last 4-vector down to vector 0 (celt_pvq_search.asm:236-251)
@@ -49,14 +46,16 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
 {
     const int nv = (N + 3) >> 2, N4 = nv * 4;
     float ax[M], fy[M];
+    unsigned long long neg = 0;                               // sign bits of x: all that is needed of it at the end
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const int i = lane + 64 * m;
         ax[m] = i < N ? fabsf(x[m]) : 0.0f;
-        if (i < N4) { L.ax[i] = ax[m]; L.s1[i] = ax[m]; }
+        neg |= (unsigned long long)(signbit(x[m]) ? 1 : 0) << m;
+        if (i < N4) L.s[i] = ax[m];
     }
     __syncthreads();
-    float c = lane < 4 ? chain_desc(L.s1, nv, lane) : 0.0f;
+    float c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
     const float Sx = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
     __syncthreads();
     if (Sx == 0.0f || Sx != Sx) {                             // comiss + jz: zero (or unordered) input
@@ -75,16 +74,21 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
         const int yt = __float2int_rn(__fmul_rn(b, ax[m]));   // cvtps2dq: round to nearest even
         fy[m] = (float)yt;
         sy += yt;
-        if (i < N4) {
-            L.fy[i] = fy[m];
-            L.s1[i] = __fmul_rn(ax[m], fy[m]);
-            L.s2[i] = __fmul_rn(fy[m], fy[m]);
-        }
+        if (i < N4) L.s[i] = __fmul_rn(ax[m], fy[m]);
     }
     __syncthreads();
-    c = lane < 4 ? chain_desc(L.s1, nv, lane) : (lane < 8 ? chain_desc(L.s2, nv, lane - 4) : 0.0f);
+    c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
     float Sxy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
-    float Syy = hsum4(__shfl(c, 4, 64), __shfl(c, 5, 64), __shfl(c, 6, 64), __shfl(c, 7, 64));
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int i = lane + 64 * m;
+        if (i < N4) L.s[i] = __fmul_rn(fy[m], fy[m]);
+    }
+    __syncthreads();
+    c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
+    float Syy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sy += __shfl_xor(sy, o, 64);   // integer: any order
     int Kr = K - sy;
@@ -127,16 +131,20 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
             const float p1 = __shfl(bp, 1, 64), p0 = __shfl(bp, 0, 64);
             const int i1 = __shfl(bi, 1, 64), i0 = __shfl(bi, 0, 64);
             const int best = !(p1 < p0) ? i1 : i0;
-            const float axb = L.ax[best], fyb = L.fy[best];
+            // the winner's |x| and pulse count live in its owner's registers: the owner (lane
+            // best & 63) picks them out, one lane read hands them round -- no LDS, no barrier
+            float axb = 0.0f, fyb = 0.0f;
+#pragma unroll
+            for (int m = 0; m < M; m++)
+                if (lane + 64 * m == best) { axb = ax[m]; fyb = fy[m]; }
+            axb = __shfl(axb, best & 63, 64);
+            fyb = __shfl(fyb, best & 63, 64);
             if (add) { Sxy = __fadd_rn(Sxy, axb); Syy = __fadd_rn(Syy, fyb); }
             else     { Sxy = __fsub_rn(Sxy, axb); Syy = __fsub_rn(Syy, fyb); }
             const float nf = add ? __fadd_rn(fyb, 1.0f) : __fsub_rn(fyb, 1.0f);
 #pragma unroll
             for (int m = 0; m < M; m++)
                 if (lane + 64 * m == best) fy[m] = nf;
-            __syncthreads();
-            if (lane == 0) L.fy[best] = nf;
-            __syncthreads();
         }
     }
 #pragma unroll
@@ -144,10 +152,9 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
         const int i = lane + 64 * m;
         if (i < N) {
             const int iv = __float2int_rn(fy[m]);
-            yout[i] = (int16_t)(signbit(x[m]) ? -iv : iv);    // orps sign, cvtps2dq
+            yout[i] = (int16_t)(((neg >> m) & 1ull) ? -iv : iv);    // orps sign, cvtps2dq
         }
     }
-    __syncthreads();
 }
 
 // bands in coding order (ffv2.c:100-120): band b = coefficients [1+BS[b], 1+BS[b+1])
@@ -183,7 +190,7 @@ struct FFV2PvqArgs {
     long long nbp;
 };
 
-__global__ __launch_bounds__(64) void ffv2_pvq_kernel(const FFV2PvqArgs a)
+__global__ __launch_bounds__(64, 3) void ffv2_pvq_kernel(const FFV2PvqArgs a)
 {
     __shared__ PvqLds L;
     const long long bp = blockIdx.x;

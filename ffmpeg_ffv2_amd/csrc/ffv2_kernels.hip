@@ -1089,6 +1089,14 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
     const int n = a.g.nblk, P = a.g.planes;
     const int i0 = blockIdx.x * EP_THREADS;
     const uint32_t *cnt = a.bitoff + (size_t)f * n;          // raw bits per block-plane (from the T-stage)
+    // this thread's 64-byte record, requested first: its latency passes behind the prefix sums
+    const int i = i0 + tid;
+    const bool have = i < n;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+    if (have) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.codes + ((size_t)f * n + i) * FFV2_CODES_PER_BP);
+        r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+    }
 
     // (1) bits in front of this workgroup, and in the whole frame; every superblock is
     // preceded by its 4 transform-type bits (ffv2enc.c:197)
@@ -1109,10 +1117,8 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
         all = scratch[4] + scratch[5] + scratch[6] + scratch[7] + 4u * (uint32_t)(n / P);
     }
 
-    const int i = i0 + tid;
-    const bool have = i < n;
     const uint32_t tx = (have && (i % P) == 0) ? 4u : 0u;
-    const uint32_t mine = have ? cnt[i] + tx : 0u;
+    const uint32_t mine = have ? r3.z + tx : 0u;              // record slot 14 = this block-plane's raw bits
     // exclusive scan of `mine` over the workgroup
     const uint32_t incl = (uint32_t)wave_iscan((int)mine);
     __syncthreads();
@@ -1149,9 +1155,6 @@ __global__ __launch_bounds__(EP_THREADS) void ffv2_estage_kernel(const FFV2EStag
 
     // (2) codes -> LDS
     if (have) {
-        // the whole 64-byte record in one go: four independent 16-byte loads, one latency
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.codes + ((size_t)f * n + i) * FFV2_CODES_PER_BP);
-        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
         const uint32_t rec[14] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
                                    r2.x, r2.y, r2.z, r2.w, r3.x, r3.y };
         LdsBitSink s;

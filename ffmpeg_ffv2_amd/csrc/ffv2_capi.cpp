@@ -16,6 +16,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -384,6 +386,70 @@ void run_parallel(int n, int want, Fn fn)
     for (auto &t : pool) t.join();
 }
 
+// A few persistent host threads that gather the rows of a caller's (pageable) frame into pinned
+// memory, slice by slice, each slice's DMA issued by the thread that gathered it.  The calling
+// thread takes part; with no workers (thread creation failed) it does everything itself.
+struct GatherPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int nslices = 0, next = 0, done = 0;
+    uint64_t gen = 0;
+    bool stop = false;
+
+    void start(int n, int device)
+    {
+        for (int t = 0; t < n; t++) {
+            try {
+                th.emplace_back([this, device]() {
+                    (void)hipSetDevice(device);
+                    uint64_t seen = 0;
+                    std::unique_lock<std::mutex> lk(mu);
+                    for (;;) {
+                        cv_work.wait(lk, [&]() { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        while (next < nslices) {
+                            const int i = next++;
+                            lk.unlock();
+                            (*job)(i);
+                            lk.lock();
+                            if (++done == nslices) cv_done.notify_all();
+                        }
+                    }
+                });
+            } catch (...) { break; }
+        }
+    }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &fn; nslices = n; next = 0; done = 0; gen++;
+        cv_work.notify_all();
+        while (next < nslices) {
+            const int i = next++;
+            lk.unlock();
+            fn(i);
+            lk.lock();
+            ++done;
+        }
+        cv_done.wait(lk, [&]() { return done == nslices; });
+        job = nullptr;
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th) t.join();
+        th.clear();
+        stop = false;
+    }
+};
+
 int pixfmt_info(int pix_fmt, int *planes, int *depth)
 {
     switch (pix_fmt) {                    // allowed_pix_fmts, ffv2enc.c:596-601
@@ -489,6 +555,7 @@ struct ffv2amd_encoder {
     std::vector<RingSlot> ring;
     int ring_head = 0, ring_count = 0;
     hipStream_t ring_h2d = nullptr, ring_comp[2] = { nullptr, nullptr }, ring_d2h = nullptr, ring_pkt = nullptr;
+    GatherPool *ring_pool = nullptr;
     unsigned ring_seq = 0;
 };
 
@@ -1305,6 +1372,7 @@ void ffv2amd_ring_close(ffv2amd_encoder *e)
         if (r.ev_meta) (void)hipEventDestroy(r.ev_meta);
     }
     e->ring.clear();
+    if (e->ring_pool) { e->ring_pool->shutdown(); delete e->ring_pool; e->ring_pool = nullptr; }
     for (hipStream_t *st : { &e->ring_h2d, &e->ring_comp[0], &e->ring_comp[1], &e->ring_d2h, &e->ring_pkt })
         if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     e->ring_head = e->ring_count = 0;
@@ -1343,6 +1411,15 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
     }
 #undef RK
     e->ring_head = e->ring_count = 0;
+    // helpers for pageable frames: a 4K plane is 16 MB of row copies, PCIe moves 55 GB/s, one host
+    // thread ~12 GB/s -- five besides the caller, fewer on a small machine, none for small pictures
+    if (e->info.frame_stride >= ((size_t)8 << 20)) {
+        unsigned hw = std::thread::hardware_concurrency();
+        static const int want = getenv("FFV2AMD_GATHER_THREADS") ? atoi(getenv("FFV2AMD_GATHER_THREADS")) : 6;   // caller included
+        const int helpers = (int)hw >= want ? want - 1 : (hw > 1 ? (int)hw - 1 : 0);
+        e->ring_pool = new (std::nothrow) GatherPool;
+        if (e->ring_pool && helpers > 0) e->ring_pool->start(helpers, e->device);
+    }
     return FFV2AMD_OK;
 }
 
@@ -1372,37 +1449,29 @@ int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const pt
                                         hipMemcpyHostToDevice, sh));
         }
     } else {
-        // pageable planes: gather into the slot's pinned frame in slices, one thread per plane;
-        // each slice's DMA overlaps the gathering of the next
-        const int slice_rows = in.height > 64 ? (in.height + 7) / 8 : in.height;
-        auto upload_plane = [&](int p) -> hipError_t {
-            for (int y0 = 0; y0 < in.height; y0 += slice_rows) {
-                const int y1 = y0 + slice_rows < in.height ? y0 + slice_rows : in.height;
-                const size_t off = (size_t)p * in.plane_stride + (size_t)y0 * in.row_pitch;
-                for (int y = y0; y < y1; y++)
-                    memcpy(r.h_frame + (size_t)p * in.plane_stride + (size_t)y * in.row_pitch,
-                           data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
-                const hipError_t rc = hipMemcpyAsync(r.d_frame + off, r.h_frame + off, (size_t)(y1 - y0) * in.row_pitch,
-                                                     hipMemcpyHostToDevice, sh);
-                if (rc != hipSuccess) return rc;
-            }
-            return hipSuccess;
+        // pageable planes: gather into the slot's pinned frame in slices of rows; every slice's DMA
+        // is issued as soon as it is gathered (by the pool's threads when the picture is large)
+        const int per_plane = e->ring_pool ? 4 : 1;
+        const int nsl = in.planes * per_plane;
+        hipError_t up[32];
+        for (int i = 0; i < nsl; i++) up[i] = hipSuccess;
+        const std::function<void(int)> slice = [&](int i) {
+            const int p = i / per_plane, k = i - p * per_plane;
+            const int y0 = (int)((long long)in.height * k / per_plane), y1 = (int)((long long)in.height * (k + 1) / per_plane);
+            if (y1 <= y0) return;
+            const size_t off = (size_t)p * in.plane_stride + (size_t)y0 * in.row_pitch;
+            for (int y = y0; y < y1; y++)
+                memcpy(r.h_frame + (size_t)p * in.plane_stride + (size_t)y * in.row_pitch,
+                       data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
+            up[i] = hipMemcpyAsync(r.d_frame + off, r.h_frame + off, (size_t)(y1 - y0) * in.row_pitch,
+                                   hipMemcpyHostToDevice, sh);
         };
-        hipError_t up[4] = { hipSuccess, hipSuccess, hipSuccess, hipSuccess };
-        bool threaded = false;
-        if (in.planes > 1 && in.plane_stride >= (size_t)4 << 20) {
-            try {
-                std::vector<std::thread> helpers;
-                for (int p = 1; p < in.planes; p++)
-                    helpers.emplace_back([&, p]() { up[p] = hipSetDevice(e->device) == hipSuccess ? upload_plane(p) : hipErrorInvalidDevice; });
-                up[0] = upload_plane(0);
-                for (auto &t : helpers) t.join();
-                threaded = true;
-            } catch (...) { threaded = false; }          // no threads to be had: gather serially
+        if (e->ring_pool) {
+            try { e->ring_pool->run(nsl, slice); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+        } else {
+            for (int i = 0; i < nsl; i++) slice(i);
         }
-        if (!threaded)
-            for (int p = 0; p < in.planes; p++) up[p] = upload_plane(p);
-        for (int p = 0; p < in.planes; p++) HIPCHK(up[p]);
+        for (int i = 0; i < nsl; i++) HIPCHK(up[i]);
     }
     const int32_t *dW = nullptr;
     if (W) {

@@ -195,7 +195,9 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
  *                  flags & FFV2AMD_FRAME_PINNED: the planes are page-locked (ffv2amd_host_alloc,
  *                  hipHostMalloc/hipHostRegister) and stay untouched until the frame's packet has
  *                  been received -- the DMA engine then reads them in place; otherwise the rows
- *                  are gathered into a pinned staging frame before send returns.
+ *                  are gathered into a pinned staging frame before send returns, by a pool of
+ *                  host threads the ring owns (FFV2AMD_GATHER_THREADS, caller included; default 6)
+ *                  that is started on the first such send and joined by ring_close.
  *   ring_receive : oldest frame in flight; FFV2AMD_ERR_AGAIN if none, or (wait == 0) not finished.
  *                  Copies back the packet's own size, not the capacity.  A frame that fails
  *                  (status < 0) is dropped from the ring and its error returned. */

@@ -468,6 +468,9 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+struct ffv2amd_encoder;
+static void lanecoder_free(ffv2amd_encoder *e);
+
 struct ffv2amd_encoder {
     ffv2amd_info info{};
     FFV2Geom geom{};
@@ -557,6 +560,17 @@ struct ffv2amd_encoder {
     hipStream_t ring_h2d = nullptr, ring_comp[2] = { nullptr, nullptr }, ring_d2h = nullptr, ring_pkt = nullptr;
     GatherPool *ring_pool = nullptr;
     unsigned ring_seq = 0;
+    // qp > 0 coder with many frames in flight (ffv2amd_lanecoder_*, ffv2_lanecoder.hip)
+    struct LaneCoder {
+        int cap = 0;                     // frames in flight
+        FFV2LaneCoderArgs a{};           // device buffers, sized for `cap` frames
+        uint32_t *d_codes = nullptr;
+        int32_t *d_status_in = nullptr;
+        uint2 *d_split = nullptr;
+        uint32_t *h_sizes = nullptr;
+        int32_t *h_status = nullptr;
+        std::vector<void *> allocs;      // every device buffer above, for close
+    } lc;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -644,6 +658,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     ffv2_upconv_destroy(e->upconv);
     (void)hipFree(e->d_420);
     if (e->h_420) (void)hipHostFree(e->h_420);
+    lanecoder_free(e);
     for (auto &q : e->qset) {
         (void)hipFree(q.d_rec); (void)hipFree(q.d_stream); (void)hipFree(q.d_totals); (void)hipFree(q.d_codes); (void)hipFree(q.d_status);
         if (q.h_rec) (void)hipHostFree(q.h_rec);
@@ -1099,6 +1114,172 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
 // as its stream has arrived.  Two batches may be in flight: submit(n+1) before finish(n)
 // overlaps the host coder with the GPU.  1 <= qp <= 64.
 // ------------------------------------------------------------------
+// ------------------------------------------------------------------
+// qp > 0 with many frames in flight (ffv2_lanecoder.hip).  The range coder is one dependent chain
+// per frame (ffv2enc.c:461,466), so throughput on the device comes from coding many frames side by
+// side, one per lane: open(F) sizes the coder's HBM scratch for F frames (about 34 bytes per
+// coefficient: 70 MB per 1080p frame), encode() takes up to F device-resident frames through
+// T-stage, PVQ search and the symbol bookkeeping max_batch frames at a time, then runs the CDF,
+// chain and packet kernels over all of them at once and brings the packets back.
+// ------------------------------------------------------------------
+static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
+{
+    auto &lc = e->lc;
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes, F = (size_t)frames, nsb = (size_t)in.num_sb_x * in.num_sb_y;
+    auto dev = [&](auto **p, size_t bytes) {
+        if (hipMalloc((void **)p, bytes) != hipSuccess) { *p = nullptr; return false; }
+        try { lc.allocs.push_back((void *)*p); } catch (...) { (void)hipFree((void *)*p); *p = nullptr; return false; }
+        return true;
+    };
+    FFV2LaneCoderArgs &a = lc.a;
+    a.nblk = (int)nb; a.planes = in.planes;
+    int width = 1;
+    while (width < frames && width < 64) width <<= 1;
+    a.width = width;
+    const size_t groups = (F + width - 1) / width;
+    const size_t maxsym = ((1 + nsb + nb * 4097) + 15) / 16 * 16;
+    a.group_stride = maxsym * (size_t)width;                       // uint2 per group
+    a.row_stride = (nb * 4097 + 255) / 256 * 256;
+    a.raw_words = (uint32_t)(in.packet_cap_qp / 4 + 4);
+    a.wcap = (uint32_t)(in.packet_cap_qp / 2 + 8);
+    a.packet_stride = in.packet_cap_qp;
+    bool ok = dev(&lc.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
+           && dev(&lc.d_status_in, sizeof(int32_t) * F) && dev(&a.abort_, sizeof(int32_t) * F)
+           && dev(&a.cnt, sizeof(FFV2SymRec) * nb * F) && dev(&a.bits, sizeof(uint32_t) * nb * F)
+           && dev(&a.rowbase, sizeof(uint32_t) * 13 * (nb + 1) * F) && dev(&a.gbase, sizeof(uint32_t) * (nb + 1) * F)
+           && dev(&a.rawbase, sizeof(uint32_t) * (nb + 1) * F) && dev(&a.delta, sizeof(uint32_t) * 13 * nb * F)
+           && dev(&a.rows, a.row_stride * F) && dev(&a.recs, sizeof(uint2) * a.group_stride * groups)
+           && dev(&a.raw, sizeof(uint32_t) * a.raw_words * F) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
+           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.packets, a.packet_stride * F)
+           && dev(&a.sizes, sizeof(uint32_t) * F) && dev(&a.status, sizeof(int32_t) * F)
+           && dev(&lc.d_split, sizeof(uint2) * nsb);
+    if (!ok) return FFV2AMD_ERR_NOMEM;
+    a.codes = lc.d_codes; a.status_in = lc.d_status_in; a.split = lc.d_split;
+    HIPCHK(hipHostMalloc(&lc.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&lc.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
+    // the symbols that carry no data: "no split" of every superblock (ffv2enc.c:222; the CDF of
+    // daala_entropy.h:140-161 advances by itself), the range-coded part of the header (ffv2enc.c:449)
+    std::vector<uint2> split;
+    try { split.resize(nsb); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    uint32_t cdf[4] = { 32, 64, 96, 128 };
+    for (size_t i = 0; i < nsb; i++) {
+        const uint32_t ft = cdf[3];
+        const int sc = 15 - RangeEnc::ilog(ft - 1);
+        split[i] = make_uint2((cdf[0] << sc) << 16, ft << sc);
+        if (cdf[3] + 128 > 32767)
+            for (int k = 0; k < 4; k++) cdf[k] = (cdf[k] >> 1) + k + 1;
+        for (int k = 0; k < 4; k++) cdf[k] += 128;
+    }
+    HIPCHK(hipMemcpy(lc.d_split, split.data(), sizeof(uint2) * nsb, hipMemcpyHostToDevice));
+    const uint32_t hs = (uint32_t)in.pix_fmt >> 4;
+    auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
+    a.header = make_uint2((hs ? q15(hs) : 0u) | (q15(hs + 1) << 16), 32768u);
+    lc.cap = frames;
+    return FFV2AMD_OK;
+}
+
+static void lanecoder_free(ffv2amd_encoder *e)
+{
+    auto &lc = e->lc;
+    for (void *p : lc.allocs) (void)hipFree(p);
+    lc.allocs.clear();
+    if (lc.h_sizes) (void)hipHostFree(lc.h_sizes);
+    if (lc.h_status) (void)hipHostFree(lc.h_status);
+    lc = ffv2amd_encoder::LaneCoder{};
+}
+
+int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight)
+{
+    if (!e || frames_in_flight < 1 || frames_in_flight > (1 << 20)) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    if (e->lc.cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        lanecoder_free(e);
+    }
+    const int r = lanecoder_alloc(e, frames_in_flight);
+    if (r < 0) lanecoder_free(e);
+    return r;
+}
+
+int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    if (e->lc.cap) (void)hipStreamSynchronize(e->stream);
+    lanecoder_free(e);
+    return FFV2AMD_OK;
+}
+
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e)
+{
+    if (!e) return 0;
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes, nsb = (size_t)in.num_sb_x * in.num_sb_y;
+    return ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + (nb * 4097 + 255) / 256 * 256
+         + in.packet_cap_qp * 4 + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
+}
+
+int ffv2amd_lanecoder_encode(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W,
+                             uint8_t *h_packets, size_t packet_stride, uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !d_frames || !h_packets || !h_sizes || !h_status || nframes < 1) return FFV2AMD_ERR_INVAL;
+    if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
+    auto &lc = e->lc;
+    if (nframes > lc.cap) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const ffv2amd_info &in = e->info;
+    const size_t nb = (size_t)in.block_planes, B = (size_t)in.max_batch;
+    if (!e->d_coef_ws) {
+        HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
+        HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
+    }
+    hipStream_t s = e->stream;
+    FFV2LaneCoderArgs a = lc.a;
+    a.qp = qp;
+    {   // raw header: pix_fmt & 15, then Exp-Golomb(qp) (ffv2enc.c:449-450)
+        const uint32_t v = (uint32_t)qp + 1u;
+        const int nbits = 31 - __builtin_clz(v);
+        uint32_t code = 1u << (2 * nbits);
+        for (int i = 0; i < nbits; i++) code |= ((v >> i) & 1u) << (2 * (nbits - 1 - i) + 1);
+        a.header_bits = ((uint32_t)in.pix_fmt & 15u) | (code << 4);
+        a.header_nbits = 4u + 2u * (uint32_t)nbits + 1u;
+    }
+    HIPCHK(hipMemsetAsync(lc.d_status_in, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(a.abort_, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(a.raw, 0, sizeof(uint32_t) * a.raw_words * (size_t)nframes, s));
+    for (int f0 = 0; f0 < nframes; f0 += (int)B) {
+        const int n = nframes - f0 < (int)B ? nframes - f0 : (int)B;
+        FFV2TStageArgs t{};
+        t.g = e->geom; t.nframes = n; t.frames = (const uint8_t *)d_frames + (size_t)f0 * in.frame_stride;
+        t.coef = e->d_coef_ws; t.energy = nullptr; t.codes = lc.d_codes + (size_t)f0 * nb * FFV2_CODES_PER_BP;
+        t.bitcnt = e->d_bitoff; t.W = d_W ? d_W + (size_t)f0 * nb : nullptr;
+        t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = lc.d_status_in + f0;
+        HIPCHK(ffv2_launch_tstage(t, s));
+        HIPCHK(ffv2_launch_pvq(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, s));
+        a.f0 = f0;
+        HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, s));
+    }
+    HIPCHK(ffv2_launch_lc_back(a, nframes, s));
+    HIPCHK(hipMemcpyAsync(lc.h_sizes, a.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(lc.h_status, a.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int f = 0; f < nframes; f++) {
+        h_status[f] = lc.h_status[f];
+        h_sizes[f] = 0;
+        if (h_status[f] < 0) continue;
+        if (lc.h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
+        h_sizes[f] = lc.h_sizes[f];
+        HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, a.packets + (size_t)f * a.packet_stride, h_sizes[f],
+                              hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return FFV2AMD_OK;
+}
+
 static int qp_alloc(ffv2amd_encoder *e)
 {
     const ffv2amd_info &in = e->info;

@@ -96,3 +96,38 @@ struct FFV2RangeCoderArgs {
     int nblk, nsb, planes, pix_fmt, qp;
 };
 hipError_t ffv2_launch_rangecoder(const FFV2RangeCoderArgs &a, int nframes, hipStream_t s);
+
+// qp > 0 entropy coder with many frames in flight (ffv2_lanecoder.hip): the serial range chain
+// runs one frame per lane, everything else is data parallel.  Frames in flight are numbered
+// 0..F-1; `width` of them share a wavefront of the chain kernel.
+struct FFV2LaneState { uint32_t T, rng, low32, last_word; };
+struct FFV2LaneCoderArgs {
+    int nblk, planes, qp, width, f0;
+    const uint32_t *codes;            // [F][nblk][16] T-stage records
+    const int32_t *status_in;         // [F] T-stage status
+    int32_t *abort_;                  // [F] != 0: the reference would av_assert0 (daala_entropy.c:336)
+    FFV2SymRec *cnt;                  // [F][nblk] count[13] = pulses read per band, offset = their sum
+    uint32_t *bits;                   // [F][nblk] raw bits of the block-plane
+    uint32_t *rowbase;                // [F][13][nblk+1]
+    uint32_t *gbase;                  // [F][nblk+1]
+    uint32_t *rawbase;                // [F][nblk+1]
+    uint32_t *delta;                  // [F][13][nblk] coding-order index minus row index of a band's first symbol
+    uint8_t *rows;                    // [F][row_stride] |pulse| per CDF row, rows back to back
+    size_t row_stride;
+    uint2 *recs;                      // coding-order records {fl | fh << 16, ft}, interleaved (lc_record)
+    size_t group_stride;              // uint2 per group of `width` frames
+    const uint2 *split;               // [superblocks] the data-independent "no split" symbols (ffv2enc.c:222)
+    uint2 header;                     // ff_daalaent_encode_uint(pix_fmt, 196)'s range-coded part (ffv2enc.c:449)
+    uint32_t header_bits, header_nbits; // raw: pix_fmt & 15, Exp-Golomb(qp)
+    uint32_t *raw;                    // [F][raw_words] raw-bit tail, LSB first, cleared beforehand
+    uint32_t raw_words;
+    uint32_t *words;                  // [F][wcap] the range code as anchored 32-bit words
+    uint32_t wcap;
+    FFV2LaneState *state;             // [F]
+    uint8_t *packets;                 // [F][packet_stride]
+    size_t packet_stride;
+    uint32_t *sizes;                  // [F]
+    int32_t *status;                  // [F]
+};
+hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
+hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s);                      // cdf, chain, finish of frames 0..nframes-1

@@ -1,0 +1,494 @@
+// ffv2_lanecoder.hip -- the qp > 0 entropy coder with MANY FRAMES IN FLIGHT (SURVEY.md 8(f) rank 1,
+// 8/A14): Daala's adaptive range coder (reference libavcodec/daala_entropy.c) is one dependent
+// chain per frame (ffv2enc.c:461,466: one coder, one set of CDF rows per frame), so the device
+// runs that chain for 64 frames per wavefront, one frame per lane, and does everything else in
+// parallel.  tools/lanecoder_model.py is the arithmetic of this file in plain Python.
+//
+//   count    per block-plane: how many pulses of each band the coder reads (ffv2enc.c:176-186:
+//            until the band's pulse count reaches qp), how many of them are non-zero, the raw
+//            bits the block-plane emits.
+//   scan     per frame: prefix sums over the block-planes -> where every band starts in its CDF
+//            row's symbol sequence, in the frame's coding order and in the raw-bit tail.
+//   scatter  per block-plane: |pulse| into the 13 per-row symbol sequences; Exp-Golomb codes and
+//            sign bits into the raw-bit tail (ffv2enc.c:105-123,148-150,174,183-184;
+//            daala_entropy.c:227-270).
+//   cdf      per (frame, CDF row): the adaptive rows advance with the symbols alone
+//            (daala_entropy.c:428-440), never with the range: between two halvings a row is its
+//            value at the last halving plus 64 x a prefix count, so 64 symbols at a time get
+//            their (fl, fh, ft) from ballots; written as records in coding order.
+//   chain    per 64 frames, lane = frame: the interval update (daala_entropy.c:362-378) and the
+//            renormalisation shift (:107-151) -- the only serial part.  `low` is not carried:
+//            the code is sum_k u_k << (T - D_k) (D_k = shifts before symbol k), accumulated into
+//            32-bit words anchored every 16 bits of depth; a symbol shifts by <= 15 bits, so the
+//            anchor advances by 0 or 1 per symbol and every word is stored exactly once.
+//   finish   per frame: ff_daalaent_encode_done's rounding (:624-674) as one more addend, the
+//            words to bytes through a one-bit carry look-ahead (:706-715), the raw bytes behind
+//            them in reverse order (:676-721).
+// PARITY UNPINNED, as all of qp > 0; tests hold this coder to the host coder's and
+// the oracle's packets.
+#include "ffv2_kernels.h"
+
+namespace {
+
+__constant__ int LC_BS[FFV2_NUM_BANDS + 1] = { 0, 15, 23, 31, 63, 95, 127, 255, 383, 511, 1023, 1535, 2047, 4096 };
+
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)       // set bits of m below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Records in coding order, interleaved so that the chain kernel's loads coalesce: frames are
+// grouped `width` at a time (one lane each); symbol k of lane L sits in piece k/8 (64 bytes per
+// lane, pieces of all lanes side by side), slot k%8.
+__device__ __forceinline__ uint2 *lc_record(uint2 *recs, size_t group_stride, int width, int f, uint32_t k)
+{
+    const int g = f / width, L = f - g * width;
+    return recs + (size_t)g * group_stride + ((size_t)(k >> 3) * width + L) * 8 + (k & 7u);
+}
+
+// Exp-Golomb code of ffv2enc.c:105-123 as the bits it appends (LSB first): for every bit of
+// val+1 below its MSB, MSB first: a 0 then the bit; then a 1.
+__device__ __forceinline__ unsigned long long golomb_code(uint32_t val, int *len)
+{
+    const uint32_t v = val + 1u;
+    if (v == 0) { *len = 0; return 0; }                       // val = 2^32-1 cannot occur (gains < 2^16, |c0| < 2^31)
+    const int nb = 31 - __clz(v);
+    unsigned long long code = 1ull << (2 * nb);
+    for (int i = 0; i < nb; i++) code |= (unsigned long long)((v >> i) & 1u) << (2 * (nb - 1 - i) + 1);
+    *len = 2 * nb + 1;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// count
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lc_count_kernel(const int16_t *y, const uint32_t *codes, int qp, int nblk,
+                                                      FFV2SymRec *cnt, uint32_t *bits, int32_t *abort_)
+{
+    const int f = blockIdx.y, bp = blockIdx.x, lane = threadIdx.x;
+    const int16_t *yy = y + ((size_t)f * nblk + bp) * FFV2_Y_STRIDE;
+    FFV2SymRec *r = cnt + (size_t)f * nblk + bp;
+    uint32_t total = 0, nz = 0;
+    bool big = false;
+#pragma unroll 1
+    for (int b = 0; b < FFV2_NUM_BANDS; b++) {
+        const int lo = 1 + LC_BS[b], N = LC_BS[b + 1] - LC_BS[b];
+        int run = 0, stop = N;
+        for (int j0 = 0; j0 < N && stop == N; j0 += 64) {
+            const int j = j0 + lane;
+            int a = j < N ? yy[lo + j] : 0;
+            a = a < 0 ? -a : a;
+            int incl = a;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const unsigned long long hit = __ballot(run + incl >= qp);
+            int end = N;
+            if (hit) { stop = j0 + __ffsll((long long)hit); end = stop; }
+            nz += (uint32_t)__popcll(__ballot(j < end && a > 0));
+            big = big || __ballot(j < end && a >= qp) != 0;       // the reference asserts (daala_entropy.c:336)
+            run += __shfl(incl, 63, 64);
+        }
+        if (stop > N) stop = N;
+        if (lane == 0) r->count[b] = (uint16_t)stop;
+        total += (uint32_t)stop;
+    }
+    if (lane == 0) {
+        r->offset = total;
+        r->pad = 0;
+        bits[(size_t)f * nblk + bp] = codes[((size_t)f * nblk + bp) * FFV2_CODES_PER_BP + 14] + nz;
+        if (big) atomicOr((int *)&abort_[f], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan: one wavefront per (quantity, frame)
+//   q < 13 : rowbase[q][bp] = symbols of CDF row q in front of block-plane bp; [nblk] = row length
+//   q = 13 : gbase[bp] = coding-order index of bp's first band symbol (1 header symbol, one split
+//            symbol per superblock in front of its first plane); [nblk] = symbols in the frame
+//   q = 14 : rawbase[bp] = bit offset of bp's first raw bit (header bits, 4 tx bits per superblock
+//            in front of its first plane); [nblk] = raw bits in the frame
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lc_scan_kernel(const FFV2LaneCoderArgs a)
+{
+    const int q = blockIdx.x, f = a.f0 + blockIdx.y, lane = threadIdx.x;
+    const int nb = a.nblk;
+    const FFV2SymRec *cnt = a.cnt + (size_t)f * nb;
+    const uint32_t *bits = a.bits + (size_t)f * nb;
+    uint32_t *out = q < 13 ? a.rowbase + ((size_t)f * 13 + q) * (nb + 1)
+                  : q == 13 ? a.gbase + (size_t)f * (nb + 1) : a.rawbase + (size_t)f * (nb + 1);
+    uint32_t run = q == 13 ? 1u : q == 14 ? a.header_nbits : 0u;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int bp = b0 + lane;
+        uint32_t v = 0, lead = 0;
+        if (bp < nb) {
+            v = q < 13 ? cnt[bp].count[q] : q == 13 ? cnt[bp].offset : bits[bp];
+            if (q >= 13 && bp % a.planes == 0) lead = q == 13 ? 1u : 4u;
+        }
+        uint32_t incl = v + lead;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (bp < nb) out[bp] = run + incl - v;                     // exclusive, behind this block-plane's lead
+        run += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    if (lane == 0) out[nb] = run;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scatter
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs a, const int16_t *y)
+{
+    __shared__ uint32_t sink[64];
+    const int fl = blockIdx.y, f = a.f0 + fl, bp = blockIdx.x, lane = threadIdx.x;
+    const int nb = a.nblk;
+    const int16_t *yy = y + ((size_t)fl * nb + bp) * FFV2_Y_STRIDE;
+    const FFV2SymRec *r = a.cnt + (size_t)f * nb + bp;
+    const uint32_t *cr = a.codes + ((size_t)f * nb + bp) * FFV2_CODES_PER_BP;
+    const uint32_t *rowbase = a.rowbase + (size_t)f * 13 * (nb + 1);
+    const uint32_t gb = a.gbase[(size_t)f * (nb + 1) + bp];
+    const uint32_t bit0 = a.rawbase[(size_t)f * (nb + 1) + bp];
+    uint8_t *rows = a.rows + (size_t)f * a.row_stride;
+    uint32_t *raw = a.raw + (size_t)f * a.raw_words;
+
+    sink[lane] = 0;
+    __syncthreads();
+    // raw bits of this block-plane, assembled at their bit offset modulo 32 (ffv2enc.c:148-150,174,183-184)
+    uint32_t pos = bit0 & 31u;
+    auto put = [&](unsigned long long code, int len) {             // lane 0
+        if (lane == 0 && len > 0) {
+            const uint32_t w = pos >> 5, s = pos & 31u;
+            atomicOr(&sink[w], (uint32_t)(code << s));
+            const unsigned long long hi = s ? code >> (32 - s) : code >> 32;   // bits past the first word
+            if (s) { if ((uint32_t)hi) atomicOr(&sink[w + 1], (uint32_t)hi); if (hi >> 32) atomicOr(&sink[w + 2], (uint32_t)(hi >> 32)); }
+            else if ((uint32_t)hi) atomicOr(&sink[w + 1], (uint32_t)hi);
+        }
+        pos += (uint32_t)len;
+    };
+    {
+        const int c0 = (int)cr[0];
+        int len;
+        const unsigned long long code = golomb_code(c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0, &len);
+        put(code, len);
+        if (c0) put(c0 < 0 ? 1u : 0u, 1);
+    }
+    uint32_t rowoff = 0, before = 0;
+#pragma unroll 1
+    for (int b = 0; b < FFV2_NUM_BANDS; b++) {
+        const int lo = 1 + LC_BS[b];
+        const uint32_t cntb = r->count[b];
+        const uint32_t rb = rowbase[(size_t)b * (nb + 1) + bp];
+        if (lane == 0) a.delta[((size_t)f * 13 + b) * nb + bp] = gb + before - rb;
+        int len;
+        const unsigned long long code = golomb_code(cr[1 + b], &len);
+        put(code, len);
+        uint8_t *dst = rows + rowoff + rb;
+        for (uint32_t j0 = 0; j0 < cntb; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const int q = j < cntb ? yy[lo + j] : 0;
+            if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
+            const unsigned long long nzm = __ballot(q != 0);
+            if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
+            pos += (uint32_t)__popcll(nzm);
+        }
+        rowoff += rowbase[(size_t)b * (nb + 1) + nb];
+        before += cntb;
+    }
+    __syncthreads();
+    {
+        const uint32_t nwords = (pos + 31u) >> 5, w0 = bit0 >> 5;
+        if ((uint32_t)lane < nwords && sink[lane] && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
+    }
+    // the symbols that carry no data: header, one "no split" per superblock, the padding of the last piece
+    if (lane == 0) {
+        if (bp % a.planes == 0) *lc_record(a.recs, a.group_stride, a.width, f, gb - 1) = a.split[bp / a.planes];
+        if (bp == 0) {
+            *lc_record(a.recs, a.group_stride, a.width, f, 0) = a.header;
+            atomicOr(&raw[0], a.header_bits);
+        }
+    }
+    if (bp == nb - 1) {
+        const uint32_t nsym = a.gbase[(size_t)f * (nb + 1) + nb];
+        const uint32_t k = nsym + (uint32_t)lane;
+        if (lane < 16 && k < ((nsym + 15u) & ~15u))
+            *lc_record(a.recs, a.group_stride, a.width, f, k) = make_uint2(0x80000000u, 0x8000u);   // fl 0, fh = ft = 32768
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cdf: one wavefront per (CDF row, frame)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
+{
+    __shared__ uint32_t flag[66];
+    const int b = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+    if (a.abort_[f] || a.status_in[f] < 0) return;
+    const int nb = a.nblk, n = a.qp;
+    const uint32_t *rowbase = a.rowbase + ((size_t)f * 13 + b) * (nb + 1);
+    const uint32_t L = rowbase[nb];
+    uint32_t rowoff = 0;
+    for (int i = 0; i < b; i++) rowoff += a.rowbase[((size_t)f * 13 + i) * (nb + 1) + nb];
+    const uint8_t *src = a.rows + (size_t)f * a.row_stride + rowoff;
+    const uint32_t *delta = a.delta + ((size_t)f * 13 + b) * nb;
+
+    uint32_t R = (uint32_t)lane + 1u;            // lane i: entry i of the row (daalaent_cdf_alloc(13, qp, 64, 0, 6, 0))
+    uint32_t F0 = (uint32_t)n;                   // entry n-1: advances with the symbol count alone
+    uint32_t k0 = 0, bp_cur = 0;
+    auto chunk_len = [&](uint32_t F, uint32_t k, bool *halve) {
+        // symbols until (and including) the one whose update halves the row (daala_entropy.c:434)
+        const uint32_t th = F + 64u > 32767u ? 0u : (32768u - 64u - F + 63u) >> 6;
+        uint32_t m = L - k < 64u ? L - k : 64u;
+        *halve = th + 1u <= m;
+        return *halve ? th + 1u : m;
+    };
+    bool halve = false;
+    uint32_t m = k0 < L ? chunk_len(F0, k0, &halve) : 0u;
+    uint32_t x = (uint32_t)lane < m ? src[k0 + lane] : 255u;
+    while (k0 < L) {
+        // the next chunk's symbols are on their way while this one is worked on
+        const uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
+        const uint32_t k1 = k0 + m;
+        bool halve1 = false;
+        const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
+        const uint32_t x1 = (uint32_t)lane < m1 ? src[k1 + lane] : 255u;
+
+        // prefix counts: symbols of this chunk in front of lane t with value <= v
+        uint32_t cl = 0, ch = 0, ca = 0;
+        for (int v = 0; v < n; v++) {
+            const unsigned long long mask = __ballot(x <= (uint32_t)v);
+            const uint32_t pc = lane_prefix(mask);
+            if ((uint32_t)v + 1u == x) cl = pc;
+            if ((uint32_t)v == x) ch = pc;
+            if (v == lane) ca = (uint32_t)__popcll(mask);
+        }
+        const uint32_t Rlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1u) << 2), (int)R);
+        const uint32_t Rhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(x << 2), (int)R);
+        uint32_t fl = x ? Rlo + 64u * cl : 0u, fh = Rhi + 64u * ch, ft = F0 + 64u * (uint32_t)lane;
+        const int sc = __clz(ft - 1u) - 17;                          // 15 - ilog(ft - 1), daala_entropy.c:346
+        fl <<= sc; fh <<= sc; ft <<= sc;
+
+        // which block-plane a symbol belongs to: the segment ends inside this chunk, as flags
+        const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
+        const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
+        const uint32_t rel = rb - k0;                                  // > 0: bp_cur holds symbol k0
+        flag[lane] = 0;
+        if (lane < 2) flag[64 + lane] = 0;
+        __syncthreads();
+        if (idx <= (uint32_t)nb && rel <= 64u) flag[rel] = 1;
+        __syncthreads();
+        const uint32_t mine = flag[lane];
+        const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
+        if ((uint32_t)lane < m) {
+            if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
+            else {
+                const uint32_t gp = k0 + (uint32_t)lane + delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
+                *lc_record(a.recs, a.group_stride, a.width, f, gp) = make_uint2(fl | (fh << 16), ft);
+            }
+        }
+        bp_cur += (uint32_t)__popcll(__ballot(idx <= (uint32_t)nb && rel <= m));
+
+        // the row after this chunk (daala_entropy.c:434-439)
+        const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)m - 1);
+        const uint32_t ge = lastx <= (uint32_t)lane ? 1u : 0u;
+        if (halve) R = ((R + 64u * (ca - ge)) >> 1) + (uint32_t)lane + 1u + 64u * ge;
+        else R += 64u * ca;
+        F0 = F1; k0 = k1; m = m1; halve = halve1; x = x1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain: lane = frame
+// ---------------------------------------------------------------------------------------------
+struct LcChain {
+    uint32_t rng, low32, D, cur, acc;
+};
+
+__device__ __forceinline__ void lc_step(LcChain &s, uint32_t lo, uint32_t hi, uint32_t *words, uint32_t wcap)
+{
+    uint32_t fl = lo & 0xFFFFu, fh = lo >> 16, ft = hi;
+    const uint32_t sc = (s.rng - ft) >= ft ? 1u : 0u;                 // daala_entropy.c:362-378
+    fl <<= sc; fh <<= sc; ft <<= sc;
+    const uint32_t d = s.rng - ft;
+    const uint32_t g = __builtin_elementwise_sub_sat(2u * d, ft);
+    const uint32_t bl = __builtin_elementwise_sub_sat(fl, g) >> 1, bh = __builtin_elementwise_sub_sat(fh, g) >> 1;
+    const uint32_t u = fl + (fl < g ? fl : g) + (bl < d ? bl : d);
+    const uint32_t v = fh + (fh < g ? fh : g) + (bh < d ? bh : d);
+    const uint32_t r = v - u;
+    const uint32_t dd = (uint32_t)__clz(r) - 16u;                      // 16 - ilog(r), :107-151
+    s.rng = r << dd;
+    const uint32_t a = s.D + 14u, w = a >> 4, o = ~a & 15u;
+    if (w != s.cur) {                                                  // the anchor moved on: the word behind is final
+        if (s.cur < wcap) words[s.cur] = s.acc;
+        s.acc = 0; s.cur = w;
+    }
+    s.acc += u << o;
+    s.low32 = (s.low32 + u) << dd;
+    s.D += dd;
+}
+
+__global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a, int nframes)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int f = g * a.width + lane;
+    const bool live = lane < a.width && f < nframes;
+    uint32_t nsym = 0;
+    if (live && a.abort_[f] == 0 && a.status_in[f] >= 0) nsym = a.gbase[(size_t)f * (a.nblk + 1) + a.nblk];
+    const uint32_t ntiles = (nsym + 15u) >> 4;
+    uint32_t maxt = ntiles;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)maxt, o, 64); maxt = t > maxt ? t : maxt; }
+    const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)g * a.group_stride) + (size_t)(live ? lane : 0) * 4;
+    const size_t piece = (size_t)a.width * 4;                          // uint4 per piece row (64 bytes per lane)
+    uint32_t *words = a.words + (size_t)(live ? f : 0) * a.wcap;
+    LcChain s{ 0x8000u, 0u, 0u, 0u, 0u };
+    uint4 buf[2][8];
+    if (maxt > 0 && 0 < ntiles) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) buf[0][i] = base[(size_t)(i >> 2) * piece + (i & 3)];
+    }
+    for (uint32_t t = 0; t < maxt; t += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t tt = t + h;
+            if (tt + 1 < ntiles) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) buf[h ^ 1][i] = base[((size_t)(tt + 1) * 2 + (i >> 2)) * piece + (i & 3)];
+            }
+            if (tt < ntiles) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    lc_step(s, buf[h][i].x, buf[h][i].y, words, a.wcap);
+                    lc_step(s, buf[h][i].z, buf[h][i].w, words, a.wcap);
+                }
+            }
+        }
+    }
+    if (live) {
+        // the last word, and two clear ones behind it for the final rounding to land in
+        if (s.cur < a.wcap) words[s.cur] = s.acc;
+        if (s.cur + 1 < a.wcap) words[s.cur + 1] = 0;
+        if (s.cur + 2 < a.wcap) words[s.cur + 2] = 0;
+        FFV2LaneState st;
+        st.T = s.D; st.rng = s.rng; st.low32 = s.low32; st.last_word = s.cur;
+        a.state[f] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finish: one workgroup per frame
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lc_bytesum(const uint32_t *W, uint32_t i)
+{
+    // word w holds the code bits of bytes 2w+1 (bits 0-7), 2w (8-15), 2w-1 (16-23), 2w-2 (24-31)
+    const uint32_t w = i >> 1, a = W[w], b = W[w + 1];
+    return (i & 1u) ? (a & 255u) + ((b >> 16) & 255u) : ((a >> 8) & 255u) + (b >> 24);
+}
+
+__global__ __launch_bounds__(256) void lc_finish_kernel(const FFV2LaneCoderArgs a)
+{
+    __shared__ uint32_t fn[256];
+    __shared__ uint32_t cin[256];
+    __shared__ uint32_t sh_nbytes, sh_slack, sh_top;
+    __shared__ int sh_status;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    uint32_t *W = a.words + (size_t)f * a.wcap;
+    const uint32_t *raw = a.raw + (size_t)f * a.raw_words;
+    uint8_t *pkt = a.packets + (size_t)f * a.packet_stride;
+    if (tid == 0) {
+        int status = a.status_in[f] < 0 ? a.status_in[f] : (a.abort_[f] || a.qp < 2) ? -1 : 0;   // qp 1: ft = 1 < 2, daala_entropy.c:342
+        uint32_t nbytes = 0, slack = 0, top = 0;
+        if (status == 0) {
+            const FFV2LaneState st = a.state[f];
+            const uint32_t T = st.T;
+            const uint32_t npre = T >= 1u ? (T - 1u) >> 3 : 0u;
+            const int cnt = -9 + (int)(T - 8u * npre);
+            const uint32_t low = st.low32 & ((1u << (cnt + 24)) - 1u), rng = st.rng;
+            uint32_t m = 0x7FFF, e = (low + m) & ~m;                  // daala_entropy.c:624-674
+            int s = 9;
+            while ((e | m) >= low + rng) { s++; m >>= 1; e = (low + m) & ~m; }
+            s += cnt;
+            const uint32_t extra = s > 0 ? (uint32_t)(s + 7) >> 3 : 0u;
+            slack = s > 0 ? 8u * extra - (uint32_t)s : (uint32_t)(-s);
+            nbytes = npre + extra;
+            const uint32_t an = T + 14u, wT = an >> 4;
+            top = 2u * wT + 2u;
+            if (wT + 1u >= a.wcap || st.last_word + 2u >= a.wcap) status = -28;
+            else W[wT] += (e - low) << (~an & 15u);
+        }
+        sh_status = status; sh_nbytes = nbytes; sh_slack = slack; sh_top = top;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int status = sh_status;
+    if (status < 0) {
+        if (tid == 0) { a.status[f] = status; a.sizes[f] = 0; }
+        return;
+    }
+    const uint32_t nbytes = sh_nbytes, slack = sh_slack, top = sh_top;
+    const uint32_t R = a.rawbase[(size_t)f * (a.nblk + 1) + a.nblk];
+    const uint32_t nraw = R > slack ? (R - slack + 7u) >> 3 : 0u;
+    const uint32_t total = nbytes + nraw;
+    const bool leftover = 8u * nraw < R;
+    if (total > a.packet_stride || (size_t)(R + 31u) / 32u > a.raw_words || (leftover && nbytes == 0)) {
+        if (tid == 0) { a.status[f] = leftover && nbytes == 0 ? -1 : -28; a.sizes[f] = 0; }
+        return;
+    }
+    // carry look-ahead over `top` bytes (daala_entropy.c:706-715): each thread resolves its chunk from
+    // the end for carry-in 0 and 1, thread 0 composes the 256 two-bit functions
+    const uint32_t per = (top + 255u) / 256u;
+    const uint32_t i0 = (uint32_t)tid * per, i1 = i0 + per < top ? i0 + per : top;
+    uint32_t k0 = 0, k1 = 1;
+    for (uint32_t i = i1; i-- > i0;) {
+        const uint32_t s = lc_bytesum(W, i);
+        k0 = (s + k0) >> 8; k1 = (s + k1) >> 8;
+    }
+    if (i0 >= i1) { k0 = 0; k1 = 1; }
+    fn[tid] = k0 | (k1 << 1);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t k = 0;
+        for (int t = 255; t >= 0; t--) { cin[t] = k; k = (fn[t] >> k) & 1u; }
+    }
+    __syncthreads();
+    uint32_t k = cin[tid];
+    for (uint32_t i = i1; i-- > i0;) {
+        const uint32_t s = lc_bytesum(W, i) + k;
+        if (i < nbytes) pkt[i] = (uint8_t)s;
+        k = s >> 8;
+    }
+    // raw bytes behind the range bytes in reverse write order (:676-721)
+    for (uint32_t j = (uint32_t)tid; j < nraw; j += 256u) pkt[total - 1u - j] = (uint8_t)(raw[j >> 2] >> (8u * (j & 3u)));
+    __syncthreads();
+    if (tid == 0) {
+        if (leftover) pkt[nbytes - 1u] |= (uint8_t)(raw[nraw >> 2] >> (8u * (nraw & 3u)));
+        a.status[f] = 0;
+        a.sizes[f] = total;
+    }
+}
+
+}  // namespace
+
+hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s)
+{
+    // a.f0 = index of the first of these frames among the frames in flight; y holds only these frames
+    const size_t nb = (size_t)a.nblk;
+    hipLaunchKernelGGL(lc_count_kernel, dim3((unsigned)a.nblk, (unsigned)nframes), dim3(64), 0, s,
+                       y, a.codes + (size_t)a.f0 * nb * FFV2_CODES_PER_BP, a.qp, a.nblk,
+                       a.cnt + (size_t)a.f0 * nb, a.bits + (size_t)a.f0 * nb, a.abort_ + a.f0);
+    hipLaunchKernelGGL(lc_scan_kernel, dim3(15, (unsigned)nframes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(lc_scatter_kernel, dim3((unsigned)a.nblk, (unsigned)nframes), dim3(64), 0, s, a, y);
+    return hipGetLastError();
+}
+
+hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s)
+{
+    hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(64), 0, s, a, nframes);
+    hipLaunchKernelGGL(lc_finish_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

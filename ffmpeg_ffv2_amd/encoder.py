@@ -178,6 +178,39 @@ class FFV2Encoder:
         """qp > 0: run the adaptive range coder on the device (one wavefront per frame) instead of host threads."""
         _lib.check(self._lib.ffv2amd_encoder_set_device_coder(self._h, 1 if on else 0), "set_device_coder")
 
+    # -- qp > 0 with many frames in flight (ffv2_lanecoder.hip) --
+    def lanecoder_open(self, frames_in_flight):
+        """Size the device coder's HBM scratch (lanecoder_bytes_per_frame() per frame)."""
+        _lib.check(self._lib.ffv2amd_lanecoder_open(self._h, int(frames_in_flight)), "ffv2amd_lanecoder_open")
+
+    def lanecoder_close(self):
+        _lib.check(self._lib.ffv2amd_lanecoder_close(self._h), "ffv2amd_lanecoder_close")
+
+    def lanecoder_bytes_per_frame(self):
+        return int(self._lib.ffv2amd_lanecoder_bytes_per_frame(self._h))
+
+    def lanecoder_encode(self, d_frames, qp, d_W=None, packet_stride=None, as_arrays=False):
+        """Up to frames_in_flight frames in HBM -> packets, the range coder running one frame per lane.
+        as_arrays: return (packets[F, stride] uint8, sizes, status) without raising on a failed frame."""
+        F = d_frames.shape[0]
+        cap = int(packet_stride or self.info.packet_cap_qp)
+        key = (F, cap)
+        if getattr(self, "_lc_key", None) != key:
+            self._lc_out, self._lc_key = np.empty((F, cap), np.uint8), key
+        pk = self._lc_out
+        sizes = np.zeros(F, np.uint32)
+        status = np.zeros(F, np.int32)
+        _lib.check(self._lib.ffv2amd_lanecoder_encode(
+            self._h, F, d_frames.data_ptr(), qp, d_W.data_ptr() if d_W is not None else None,
+            pk.ctypes.data_as(C.c_void_p), cap, sizes.ctypes.data_as(C.c_void_p),
+            status.ctypes.data_as(C.c_void_p)), "ffv2amd_lanecoder_encode")
+        if as_arrays:
+            return pk, sizes, status
+        for f in range(F):
+            if status[f] < 0:
+                raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
+        return [pk[f, : sizes[f]].tobytes() for f in range(F)]
+
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
         r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,

@@ -159,6 +159,27 @@ int  ffv2amd_qp_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, 
 int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                        uint32_t *h_sizes, int32_t *h_status);
 
+/* qp > 0 with MANY FRAMES IN FLIGHT (ffv2_lanecoder.hip).  The range coder
+ * is one dependent chain per frame (ffv2enc.c:461,466), so the device codes many frames side by
+ * side, one per lane of a wavefront, and does the rest (CDF rows as prefix counts, raw bits,
+ * carry propagation) data-parallel.  Throughput grows with the frames in flight until the other
+ * kernels bound it; the time of one call is at least one frame's chain (about 70 ns per symbol).
+ *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames
+ *                      (ffv2amd_lanecoder_bytes_per_frame() each: 34 bytes per coefficient,
+ *                      70 MB per 1080p frame); FFV2AMD_ERR_NOMEM if the device cannot hold it.
+ *   lanecoder_encode : up to that many device-resident frames (layout of ffv2amd_info) -> packets
+ *                      in host memory, byte-identical to ffv2amd_encode_batch_to_host at the same
+ *                      qp (1..64).  Per-frame status as there (FFV2AMD_ERR_ABORT where the
+ *                      reference would av_assert0).  Synchronous; runs on the encoder's stream.
+ * PARITY UNPINNED like all of qp > 0. */
+int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight);
+int    ffv2amd_lanecoder_close(ffv2amd_encoder *enc);
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc);
+int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp,
+                                const int32_t *d_W, uint8_t *h_packets, size_t packet_stride,
+                                uint32_t *h_sizes, int32_t *h_status);
+
+
 /* Decoder-side inverse of the T-stage (reference ffv2.c:81-98 coding_to_raster, :4962-4972
  * tx_inv_2d / od_bin_idct64, :216-239 lapping post-filter in ffv2dec.c's seam order,
  * :40-52 coeffs_2_ref): coding-order coefficients d_coef[nframes][block_planes][4096] ->

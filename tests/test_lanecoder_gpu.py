@@ -1,0 +1,98 @@
+"""GPU tests of the qp > 0 coder with many frames in flight (ffv2_lanecoder.hip, SURVEY.md 8(f) rank 1,
+8/A14): the range coder's serial chain runs one frame per lane, CDF rows / raw bits / carries are
+data-parallel.  Packets are held to the host coder's (ffv2amd_encode_batch_to_host) and the CPU
+oracle's.  Parity unpinned for qp > 0: the oracle restates the reference's PVQ asm, which cannot be
+assembled here."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from ffmpeg_ffv2_amd import frames as synth  # noqa: E402
+
+
+def _enc(w, h, fmt, max_batch):
+    from ffmpeg_ffv2_amd import FFV2Encoder, build
+    build.build()
+    return FFV2Encoder(w, h, fmt, device=0, max_batch=max_batch)
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth", [("gray", 1, 64, 64, 8), ("yuv444p", 3, 100, 150, 8),
+                                             ("yuv444p10le", 3, 130, 200, 10)])
+@pytest.mark.parametrize("qp", [2, 4, 16, 33, 64])
+def test_lanecoder_matches_host_coder_and_oracle(oracle, fmt, P, H, W, depth, qp):
+    enc = _enc(W, H, fmt, 3)
+    n = 5                                            # two T-stage batches, one partly filled group of lanes
+    frames = np.stack([synth.noise(7 * qp + i, P, H, W, depth) if i % 2 == 0 else synth.make("S1", i, P, H, W, depth)
+                       for i in range(n)])
+    dev = enc.upload(frames)
+    enc.lanecoder_open(n)
+    pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+    for i in range(n):
+        try:
+            want = oracle.encode(frames[i], fmt, qp=qp)
+        except Exception:
+            want = None                              # the reference would av_assert0 on this frame
+        if want is None:
+            assert status[i] == -1, (i, status[i])
+        else:
+            assert status[i] == 0, (i, status[i])
+            assert pk[i, : sizes[i]].tobytes() == want, i
+    enc.lanecoder_close()
+    enc.close()
+
+
+def test_lanecoder_more_frames_than_lanes(oracle):
+    """70 small frames: two groups of lanes (64 + 6), frames of different lengths side by side."""
+    W, H, fmt, P, depth, qp = 64, 128, "gray", 1, 8, 8
+    enc = _enc(W, H, fmt, 16)
+    n = 70
+    frames = np.stack([synth.noise(1000 + i, P, H, W, depth) if i % 3 else synth.make("S2", i, P, H, W, depth)
+                       for i in range(n)])
+    # frames with less to code: a quiet lower half
+    frames[5, :, 64:, :] = 120 + frames[5, :, 64:, :] % 16
+    frames[66, :, 32:, :] = 7 + frames[66, :, 32:, :] % 3
+    dev = enc.upload(frames)
+    enc.lanecoder_open(n)
+    pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+    lengths = set()
+    for i in range(n):
+        try:
+            want = oracle.encode(frames[i], fmt, qp=qp)
+        except Exception:
+            want = None
+        if want is None:
+            assert status[i] == -1, i
+        else:
+            assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == want, i
+            lengths.add(len(want))
+    assert len(lengths) > 3
+    good = [i for i in range(16) if status[i] == 0]
+    if len(good) == 16:
+        assert enc.encode_batch_to_host(dev[:16], qp=qp) == [pk[i, : sizes[i]].tobytes() for i in range(16)]
+    # a second call reuses the scratch (raw-bit tail and flags are cleared per call)
+    first = [pk[i, : sizes[i]].tobytes() for i in range(3)]
+    pk2, sizes2, status2 = enc.lanecoder_encode(dev[:3], qp, as_arrays=True)
+    assert [pk2[i, : sizes2[i]].tobytes() for i in range(3)] == first and list(status2) == list(status[:3])
+    enc.close()
+
+
+def test_lanecoder_abort_and_arguments(oracle):
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    enc = _enc(64, 64, "gray", 2)
+    flat = np.full((2, 1, 64, 64), 200, np.uint8)
+    flat[0, 0, 10, 10] = 0                           # pulses concentrate: daala_entropy.c:336
+    flat[1] = synth.noise(3, 1, 64, 64, 8)
+    dev = enc.upload(flat)
+    with pytest.raises(FFV2Error):                   # not opened
+        enc.lanecoder_encode(dev, 16)
+    enc.lanecoder_open(2)
+    pk, sizes, status = enc.lanecoder_encode(dev, 16, as_arrays=True)
+    assert status[0] == -1 and status[1] == 0
+    assert pk[1, : sizes[1]].tobytes() == oracle.encode(flat[1], "gray", qp=16)
+    # qp 1 always aborts in the reference (ft = 1, daala_entropy.c:342)
+    pk, sizes, status = enc.lanecoder_encode(dev, 1, as_arrays=True)
+    assert list(status) == [-1, -1]
+    with pytest.raises(FFV2Error):
+        enc.lanecoder_encode(dev, 65)
+    enc.close()

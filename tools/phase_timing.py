@@ -27,7 +27,7 @@ def build():
     obj = os.path.join(OUT, "ffv2_kernels_timing.o")
     subprocess.run([b._hipcc()] + b.HIPFLAGS + ["-DFFV2_PHASE_TIMING"] + (["-DFFV2_PHASE_WALL"] if WALL else []) + ["-c", os.path.join(b.CSRC, "ffv2_kernels.hip"),
                                               "-o", obj], check=True)
-    objs = [obj] + [os.path.join(b.CSRC, n) for n in ("ffv2_pvq.o", "ffv2_inverse.o", "ffv2_upconv.o", "ffv2_rangecoder.o", "ffv2_capi.o", "ffv2enc_amd.o", "ffv2mkv.o")]
+    objs = [obj] + [os.path.join(b.CSRC, n) for n in ("ffv2_pvq.o", "ffv2_inverse.o", "ffv2_upconv.o", "ffv2_rangecoder.o", "ffv2_lanecoder.o", "ffv2_capi.o", "ffv2enc_amd.o", "ffv2mkv.o")]
     subprocess.run([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs, check=True)
     print(SO)
 

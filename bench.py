@@ -90,6 +90,73 @@ def h2d_rate(dev, nbytes, reps=8):
     return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
+    """--qp N --frames-in-flight F: the qp > 0 path with the whole entropy coder on the device, the
+    range coder's serial chain running one frame per lane.  Not the BASELINE
+    metric; PARITY UNPINNED for qp > 0 (the oracle restates the reference's PVQ asm)."""
+    W, H, fmt, depth, P = cfg
+    world, rank, local, dev, backend = dist_cfg
+    enc0.close()
+    F = args.frames_in_flight
+    enc = FFV2Encoder(W, H, fmt, device=local, max_batch=16)
+    distinct = min(F, 64)
+    host_frames = np.stack([synth.noise(rank * distinct + n, P, H, W, depth) for n in range(distinct)])
+    d = enc.upload(host_frames)
+    d_frames = d.repeat((F + distinct - 1) // distinct, *([1] * (d.dim() - 1)))[:F].contiguous()
+    del d
+    enc.lanecoder_open(F)
+    pk, sizes, status = enc.lanecoder_encode(d_frames, args.qp, as_arrays=True)
+    stride = int(sizes.max()) * 5 // 4 + 4096          # host packet pitch for the timed calls
+    for _ in range(args.warmup):
+        enc.lanecoder_encode(d_frames, args.qp, packet_stride=stride, as_arrays=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pk, sizes, status = enc.lanecoder_encode(d_frames, args.qp, packet_stride=stride, as_arrays=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        res = {"metric": "Mpix/s encode, qp=%d (not the BASELINE metric; parity unpinned for qp > 0)" % args.qp,
+               "value": round(world * F * args.steps * W * H / dt / 1e6, 1), "unit": "Mpix/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "int32 + f32 (PVQ search)", "data": "synthetic",
+               "config": {"workload": "%dx%d %s qp=%d, %d frames per step per GPU (%d distinct noise frames, repeated), "
+                                      "frames resident in HBM, packets to host memory" % (W, H, fmt, args.qp, F, distinct),
+                          "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
+                          "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
+                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame() / 1e9, 1)},
+               "roofline": None}
+        if world == 1 and not args.no_cpu_baseline:
+            from tests import oracle_lib
+            oracle = oracle_lib.load()
+            n_done, tcpu, ok = 0, 0.0, True
+            while n_done < distinct and tcpu < args.cpu_seconds:
+                c0 = time.perf_counter()
+                ref = oracle.encode(host_frames[n_done], fmt, qp=args.qp)
+                tcpu += time.perf_counter() - c0
+                for i in range(n_done, F, distinct):      # every repetition of this frame
+                    ok = ok and status[i] == 0 and pk[i, : sizes[i]].tobytes() == ref
+                n_done += 1
+            res["cpu_baseline"] = {"value": round(n_done * W * H / tcpu / 1e6, 2), "unit": "Mpix/s", "cores": 1,
+                                   "kind": "port", "sample": "%d of the %d distinct benchmark frames, oracle qp=%d, 1 thread"
+                                                             % (n_done, distinct, args.qp),
+                                   "gpu_packets_match_cpu": bool(ok)}
+            if not ok:
+                res["error"] = "GPU packets differ from the CPU oracle"
+        print(json.dumps(res))
+    enc.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +176,9 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-frames-in / host-packets-out phase")
     ap.add_argument("--host-frames", type=int, default=48, help="frames per rank in the host-boundary phase")
     ap.add_argument("--ring-depth", type=int, default=4)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="with --qp: the many-frames-in-flight device coder (ffv2_lanecoder.hip, one frame per lane of the "
+                         "range chain); a step is one call over this many device-resident frames")
     ap.add_argument("--qp", type=int, default=0,
                     help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()
@@ -157,6 +227,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.qp > 0 and args.frames_in_flight > 0:
+        lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
+        return
     if args.qp > 0:
         # Not the headline metric (BASELINE's config is the default qp = 0): the qp > 0 path --
         # T-stage + PVQ search + symbol compaction on the GPU, adaptive range coder on host threads

@@ -1142,7 +1142,7 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
     a.group_stride = maxsym * (size_t)width;                       // uint2 per group
     a.row_stride = (nb * 4097 + 255) / 256 * 256;
     a.raw_words = (uint32_t)(in.packet_cap_qp / 4 + 4);
-    a.wcap = (uint32_t)(in.packet_cap_qp / 2 + 8);
+    a.wcap = (uint32_t)(in.packet_cap_qp / 2 + 32);
     a.packet_stride = in.packet_cap_qp;
     bool ok = dev(&lc.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
            && dev(&lc.d_status_in, sizeof(int32_t) * F) && dev(&a.abort_, sizeof(int32_t) * F)

@@ -100,7 +100,7 @@ hipError_t ffv2_launch_rangecoder(const FFV2RangeCoderArgs &a, int nframes, hipS
 // qp > 0 entropy coder with many frames in flight (ffv2_lanecoder.hip): the serial range chain
 // runs one frame per lane, everything else is data parallel.  Frames in flight are numbered
 // 0..F-1; `width` of them share a wavefront of the chain kernel.
-struct FFV2LaneState { uint32_t T, rng, low32, last_word; };
+struct FFV2LaneState { uint32_t woff, o, rng, full; };   // where the next symbol would land (word, bit), the range, words exhausted
 struct FFV2LaneCoderArgs {
     int nblk, planes, qp, width, f0;
     const uint32_t *codes;            // [F][nblk][16] T-stage records

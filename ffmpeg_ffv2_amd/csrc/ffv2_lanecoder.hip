@@ -20,7 +20,7 @@
 //            renormalisation shift (:107-151) -- the only serial part.  `low` is not carried:
 //            the code is sum_k u_k << (T - D_k) (D_k = shifts before symbol k), accumulated into
 //            32-bit words anchored every 16 bits of depth; a symbol shifts by <= 15 bits, so the
-//            anchor advances by 0 or 1 per symbol and every word is stored exactly once.
+//            anchor advances by 0 or 1 per symbol.
 //   finish   per frame: ff_daalaent_encode_done's rounding (:624-674) as one more addend, the
 //            words to bytes through a one-bit carry look-ahead (:706-715), the raw bytes behind
 //            them in reverse order (:676-721).
@@ -304,31 +304,36 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
 // ---------------------------------------------------------------------------------------------
 // chain: lane = frame
 // ---------------------------------------------------------------------------------------------
+// State of one frame's chain: the range, and where the next symbol's offset lands: bit `o` of
+// word `woff` (the depth of the next symbol is 16 woff + 1 - o).  `acc` is that word so far.
 struct LcChain {
-    uint32_t rng, low32, D, cur, acc;
+    uint32_t rng, o, acc, woff;
 };
 
-__device__ __forceinline__ void lc_step(LcChain &s, uint32_t lo, uint32_t hi, uint32_t *words, uint32_t wcap)
+__device__ __forceinline__ void lc_step(LcChain &s, uint32_t lo, uint32_t ft, uint32_t *words)
 {
-    uint32_t fl = lo & 0xFFFFu, fh = lo >> 16, ft = hi;
-    const uint32_t sc = (s.rng - ft) >= ft ? 1u : 0u;                 // daala_entropy.c:362-378
-    fl <<= sc; fh <<= sc; ft <<= sc;
+    // daala_entropy.c:362-378.  Scaling by two (sc) needs rng >= 2 ft, hence ft < 32768 and
+    // fh << 1 < 65536: both halves of `lo` shift in one go.
+    const uint32_t sc = (s.rng - ft) >= ft ? 1u : 0u;
+    lo <<= sc; ft <<= sc;
+    const uint32_t fl = lo & 0xFFFFu, fh = lo >> 16;
     const uint32_t d = s.rng - ft;
     const uint32_t g = __builtin_elementwise_sub_sat(2u * d, ft);
     const uint32_t bl = __builtin_elementwise_sub_sat(fl, g) >> 1, bh = __builtin_elementwise_sub_sat(fh, g) >> 1;
     const uint32_t u = fl + (fl < g ? fl : g) + (bl < d ? bl : d);
     const uint32_t v = fh + (fh < g ? fh : g) + (bh < d ? bh : d);
-    const uint32_t r = v - u;
-    const uint32_t dd = (uint32_t)__clz(r) - 16u;                      // 16 - ilog(r), :107-151
+    const uint32_t r = v - u;                                          // 1 <= r < 65536
+    const uint32_t dd = (uint32_t)__builtin_clz(r) - 16u;              // 16 - ilog(r), :107-151
     s.rng = r << dd;
-    const uint32_t a = s.D + 14u, w = a >> 4, o = ~a & 15u;
-    if (w != s.cur) {                                                  // the anchor moved on: the word behind is final
-        if (s.cur < wcap) words[s.cur] = s.acc;
-        s.acc = 0; s.cur = w;
-    }
-    s.acc += u << o;
-    s.low32 = (s.low32 + u) << dd;
-    s.D += dd;
+    // the word is stored every time; its last store stands.  A symbol shifts by <= 15 bits, so the
+    // position moves on by at most one word.
+    s.acc += u << s.o;
+    words[s.woff] = s.acc;
+    const int o2 = (int)s.o - (int)dd;
+    const bool adv = o2 < 0;
+    s.woff += adv ? 1u : 0u;
+    s.acc = adv ? 0u : s.acc;
+    s.o = (uint32_t)o2 & 15u;
 }
 
 __global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a, int nframes)
@@ -345,7 +350,8 @@ __global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a,
     const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)g * a.group_stride) + (size_t)(live ? lane : 0) * 4;
     const size_t piece = (size_t)a.width * 4;                          // uint4 per piece row (64 bytes per lane)
     uint32_t *words = a.words + (size_t)(live ? f : 0) * a.wcap;
-    LcChain s{ 0x8000u, 0u, 0u, 0u, 0u };
+    const uint32_t wlimit = a.wcap - 2u;                               // a frame that runs past its words is refused by lc_finish_kernel
+    LcChain s{ 0x8000u, 1u, 0u, 0u };
     uint4 buf[2][8];
     if (maxt > 0 && 0 < ntiles) {
 #pragma unroll
@@ -362,19 +368,19 @@ __global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a,
             if (tt < ntiles) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    lc_step(s, buf[h][i].x, buf[h][i].y, words, a.wcap);
-                    lc_step(s, buf[h][i].z, buf[h][i].w, words, a.wcap);
+                    lc_step(s, buf[h][i].x, buf[h][i].y, words);
+                    lc_step(s, buf[h][i].z, buf[h][i].w, words);
                 }
+                s.woff = s.woff < wlimit ? s.woff : wlimit;            // 16 symbols move on by <= 15 words: wcap has that slack
             }
         }
     }
     if (live) {
-        // the last word, and two clear ones behind it for the final rounding to land in
-        if (s.cur < a.wcap) words[s.cur] = s.acc;
-        if (s.cur + 1 < a.wcap) words[s.cur + 1] = 0;
-        if (s.cur + 2 < a.wcap) words[s.cur + 2] = 0;
+        // the word the next symbol would go to, and a clear one behind it
+        words[s.woff] = s.acc;
+        words[s.woff + 1] = 0;
         FFV2LaneState st;
-        st.T = s.D; st.rng = s.rng; st.low32 = s.low32; st.last_word = s.cur;
+        st.woff = s.woff; st.o = s.o; st.rng = s.rng; st.full = s.woff >= wlimit ? 1u : 0u;
         a.state[f] = st;
     }
 }
@@ -404,10 +410,15 @@ __global__ __launch_bounds__(256) void lc_finish_kernel(const FFV2LaneCoderArgs 
         uint32_t nbytes = 0, slack = 0, top = 0;
         if (status == 0) {
             const FFV2LaneState st = a.state[f];
-            const uint32_t T = st.T;
+            const uint32_t wT = st.woff, oT = st.o, rng = st.rng;
+            const uint32_t T = 16u * wT + 1u - oT;                    // all shifts so far
             const uint32_t npre = T >= 1u ? (T - 1u) >> 3 : 0u;
             const int cnt = -9 + (int)(T - 8u * npre);
-            const uint32_t low = st.low32 & ((1u << (cnt + 24)) - 1u), rng = st.rng;
+            // the coder's window (the low cnt + 24 bits of the code so far) read back from the last words
+            unsigned long long V = W[wT];
+            if (wT >= 1) V += (unsigned long long)W[wT - 1] << 16;
+            if (wT >= 2) V += (unsigned long long)W[wT - 2] << 32;
+            const uint32_t low = (uint32_t)(V >> oT) & ((1u << (cnt + 24)) - 1u);
             uint32_t m = 0x7FFF, e = (low + m) & ~m;                  // daala_entropy.c:624-674
             int s = 9;
             while ((e | m) >= low + rng) { s++; m >>= 1; e = (low + m) & ~m; }
@@ -415,10 +426,9 @@ __global__ __launch_bounds__(256) void lc_finish_kernel(const FFV2LaneCoderArgs 
             const uint32_t extra = s > 0 ? (uint32_t)(s + 7) >> 3 : 0u;
             slack = s > 0 ? 8u * extra - (uint32_t)s : (uint32_t)(-s);
             nbytes = npre + extra;
-            const uint32_t an = T + 14u, wT = an >> 4;
             top = 2u * wT + 2u;
-            if (wT + 1u >= a.wcap || st.last_word + 2u >= a.wcap) status = -28;
-            else W[wT] += (e - low) << (~an & 15u);
+            if (st.full) status = -28;
+            else W[wT] += (e - low) << oT;
         }
         sh_status = status; sh_nbytes = nbytes; sh_slack = slack; sh_top = top;
     }

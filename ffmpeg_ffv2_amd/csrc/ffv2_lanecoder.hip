@@ -239,6 +239,8 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     uint32_t R = (uint32_t)lane + 1u;            // lane i: entry i of the row (daalaent_cdf_alloc(13, qp, 64, 0, 6, 0))
     uint32_t F0 = (uint32_t)n;                   // entry n-1: advances with the symbol count alone
     uint32_t k0 = 0, bp_cur = 0;
+    uint32_t seg_end = rowbase[1], dl_cur = delta[0];      // end of the current block-plane's band in this row, its delta
+    uint2 *recs = lc_record(a.recs, a.group_stride, a.width, f, 0);   // this frame's slot 0 of piece 0
     auto chunk_len = [&](uint32_t F, uint32_t k, bool *halve) {
         // symbols until (and including) the one whose update halves the row (daala_entropy.c:434)
         const uint32_t th = F + 64u > 32767u ? 0u : (32768u - 64u - F + 63u) >> 6;
@@ -257,14 +259,19 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
         const uint32_t x1 = (uint32_t)lane < m1 ? src[k1 + lane] : 255u;
 
-        // prefix counts: symbols of this chunk in front of lane t with value <= v
+        // prefix counts: cl / ch = symbols of this chunk in front of lane t with a value below / up
+        // to lane t's own; ca (lane i as row entry i) = symbols of the chunk with value <= i.  One
+        // round per DISTINCT value in the chunk (a band's pulses are mostly 0 and 1), not per value.
         uint32_t cl = 0, ch = 0, ca = 0;
-        for (int v = 0; v < n; v++) {
-            const unsigned long long mask = __ballot(x <= (uint32_t)v);
-            const uint32_t pc = lane_prefix(mask);
-            if ((uint32_t)v + 1u == x) cl = pc;
-            if ((uint32_t)v == x) ch = pc;
-            if (v == lane) ca = (uint32_t)__popcll(mask);
+        unsigned long long rem = __ballot(x < 255u);
+        while (rem) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)x, __ffsll((long long)rem) - 1);
+            const unsigned long long mk = __ballot(x == v);
+            const uint32_t e = lane_prefix(mk);
+            if (v < x) cl += e;
+            if (v <= x) ch += e;
+            if (v <= (uint32_t)lane) ca += (uint32_t)__popcll(mk);
+            rem &= ~mk;
         }
         const uint32_t Rlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1u) << 2), (int)R);
         const uint32_t Rhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(x << 2), (int)R);
@@ -272,25 +279,40 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         const int sc = __clz(ft - 1u) - 17;                          // 15 - ilog(ft - 1), daala_entropy.c:346
         fl <<= sc; fh <<= sc; ft <<= sc;
 
-        // which block-plane a symbol belongs to: the segment ends inside this chunk, as flags
-        const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
-        const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
-        const uint32_t rel = rb - k0;                                  // > 0: bp_cur holds symbol k0
-        flag[lane] = 0;
-        if (lane < 2) flag[64 + lane] = 0;
-        __syncthreads();
-        if (idx <= (uint32_t)nb && rel <= 64u) flag[rel] = 1;
-        __syncthreads();
-        const uint32_t mine = flag[lane];
-        const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
+        // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
+        // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
+        // prefix count over them gives every lane its block-plane.
+        uint32_t dl;
+        if (seg_end - k0 >= m && seg_end - k0 > 0u) {
+            dl = dl_cur;
+            if (seg_end - k0 == m) {                                   // the band ends with this chunk
+                bp_cur++;
+                seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
+                dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
+            }
+        } else {
+            const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
+            const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
+            const uint32_t rel = rb - k0;                              // > 0: bp_cur holds symbol k0
+            flag[lane] = 0;
+            if (lane < 2) flag[64 + lane] = 0;
+            __syncthreads();
+            if (idx <= (uint32_t)nb && rel <= 64u) flag[rel] = 1;
+            __syncthreads();
+            const uint32_t mine = flag[lane];
+            const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
+            dl = delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
+            bp_cur += (uint32_t)__popcll(__ballot(idx <= (uint32_t)nb && rel <= m));
+            seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
+            dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
+        }
         if ((uint32_t)lane < m) {
             if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
             else {
-                const uint32_t gp = k0 + (uint32_t)lane + delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
-                *lc_record(a.recs, a.group_stride, a.width, f, gp) = make_uint2(fl | (fh << 16), ft);
+                const uint32_t gp = k0 + (uint32_t)lane + dl;
+                recs[((size_t)(gp >> 3) * (size_t)a.width) * 8 + (gp & 7u)] = make_uint2(fl | (fh << 16), ft);
             }
         }
-        bp_cur += (uint32_t)__popcll(__ballot(idx <= (uint32_t)nb && rel <= m));
 
         // the row after this chunk (daala_entropy.c:434-439)
         const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)m - 1);

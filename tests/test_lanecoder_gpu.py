@@ -96,3 +96,43 @@ def test_lanecoder_abort_and_arguments(oracle):
     with pytest.raises(FFV2Error):
         enc.lanecoder_encode(dev, 65)
     enc.close()
+
+
+def test_lanecoder_random_geometries_against_host_coder():
+    """Random sizes / formats / qp / content mixes: every frame's packet (or abort) must equal the
+    host coder's, frame by frame."""
+    import random
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    rnd = random.Random(20261004)
+    fmts = [("gray", 1, 8), ("yuv444p", 3, 8), ("yuv444p10le", 3, 10), ("gbrp12le", 3, 12), ("yuv444p12le", 3, 12)]
+    checked = aborted = 0
+    for it in range(24):
+        fmt, P, depth = rnd.choice(fmts)
+        W, H = rnd.randint(1, 260), rnd.randint(1, 200)
+        qp = rnd.choice([2, 3, 5, 8, 16, 17, 32, 48, 64])
+        n = rnd.randint(1, 7)
+        enc = _enc(W, H, fmt, rnd.randint(1, 3))
+        kinds = [rnd.choice(["S2", "S2", "S1", "flatnoise"]) for _ in range(n)]
+        frames = []
+        for i, k in enumerate(kinds):
+            if k == "flatnoise":
+                f = synth.noise(it * 10 + i, P, H, W, depth)
+                f = (f % 5 + (1 << (depth - 1))).astype(f.dtype)
+            else:
+                f = synth.make(k, it * 10 + i, P, H, W, depth)
+            frames.append(f)
+        frames = np.stack(frames)
+        dev = enc.upload(frames)
+        enc.lanecoder_open(n)
+        pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+        for i in range(n):
+            try:
+                want = enc.encode_batch_to_host(dev[i:i + 1], qp=qp)[0]
+            except FFV2Error as e:
+                assert status[i] == e.code, (it, i, status[i], e.code)
+                aborted += 1
+                continue
+            assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == want, (it, i, fmt, W, H, qp, kinds[i])
+            checked += 1
+        enc.close()
+    assert checked > 40 and aborted > 0

@@ -562,13 +562,24 @@ struct ffv2amd_encoder {
     unsigned ring_seq = 0;
     // qp > 0 coder with many frames in flight (ffv2amd_lanecoder_*, ffv2_lanecoder.hip)
     struct LaneCoder {
-        int cap = 0;                     // frames in flight
-        FFV2LaneCoderArgs a{};           // device buffers, sized for `cap` frames
-        uint32_t *d_codes = nullptr;
-        int32_t *d_status_in = nullptr;
+        int cap = 0;                     // frames in flight per call
+        FFV2LaneCoderArgs a{};           // geometry and the back's scratch (records, code words), sized for `cap` frames
         uint2 *d_split = nullptr;
-        uint32_t *h_sizes = nullptr;
-        int32_t *h_status = nullptr;
+        // the front's buffers, twice: call n+1's front runs beside call n's chain
+        struct Set {
+            uint32_t *d_codes = nullptr, *bits = nullptr, *rowbase = nullptr, *gbase = nullptr, *rawbase = nullptr, *delta = nullptr;
+            int32_t *d_status_in = nullptr, *abort_ = nullptr, *status = nullptr;
+            FFV2SymRec *cnt = nullptr;
+            uint8_t *rows = nullptr, *packets = nullptr;
+            uint32_t *raw = nullptr, *sizes = nullptr;
+            uint32_t *h_sizes = nullptr;
+            int32_t *h_status = nullptr;
+            hipEvent_t ev_front = nullptr, ev_done = nullptr;
+            int nframes = 0;
+            bool busy = false;
+        } set[2];
+        hipStream_t back = nullptr, copy = nullptr;
+        unsigned sub = 0, fin = 0;
         std::vector<void *> allocs;      // every device buffer above, for close
     } lc;
 };
@@ -1117,10 +1128,13 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
 // ------------------------------------------------------------------
 // qp > 0 with many frames in flight (ffv2_lanecoder.hip).  The range coder is one dependent chain
 // per frame (ffv2enc.c:461,466), so throughput on the device comes from coding many frames side by
-// side, one per lane: open(F) sizes the coder's HBM scratch for F frames (about 34 bytes per
-// coefficient: 70 MB per 1080p frame), encode() takes up to F device-resident frames through
-// T-stage, PVQ search and the symbol bookkeeping max_batch frames at a time, then runs the CDF,
-// chain and packet kernels over all of them at once and brings the packets back.
+// side, one per lane: open(F) sizes the coder's HBM scratch for F frames (about 40 bytes per
+// coefficient: 84 MB per 1080p frame).  submit() takes up to F device-resident frames through
+// T-stage, PVQ search and the symbol bookkeeping max_batch frames at a time on the encoder's
+// stream (the "front"), then queues the CDF, chain and packet kernels over all of them on a second
+// stream (the "back").  The back's scratch (records, code words) exists once, the front's twice:
+// submit(n+1) before finish(n) runs the front of call n+1 beside the chain of call n, which keeps
+// only 1/16 of the chip's SIMDs busy.
 // ------------------------------------------------------------------
 static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
 {
@@ -1144,20 +1158,27 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
     a.raw_words = (uint32_t)(in.packet_cap_qp / 4 + 4);
     a.wcap = (uint32_t)(in.packet_cap_qp / 2 + 32);
     a.packet_stride = in.packet_cap_qp;
-    bool ok = dev(&lc.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
-           && dev(&lc.d_status_in, sizeof(int32_t) * F) && dev(&a.abort_, sizeof(int32_t) * F)
-           && dev(&a.cnt, sizeof(FFV2SymRec) * nb * F) && dev(&a.bits, sizeof(uint32_t) * nb * F)
-           && dev(&a.rowbase, sizeof(uint32_t) * 13 * (nb + 1) * F) && dev(&a.gbase, sizeof(uint32_t) * (nb + 1) * F)
-           && dev(&a.rawbase, sizeof(uint32_t) * (nb + 1) * F) && dev(&a.delta, sizeof(uint32_t) * 13 * nb * F)
-           && dev(&a.rows, a.row_stride * F) && dev(&a.recs, sizeof(uint2) * a.group_stride * groups)
-           && dev(&a.raw, sizeof(uint32_t) * a.raw_words * F) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
-           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.packets, a.packet_stride * F)
-           && dev(&a.sizes, sizeof(uint32_t) * F) && dev(&a.status, sizeof(int32_t) * F)
-           && dev(&lc.d_split, sizeof(uint2) * nsb);
+    bool ok = dev(&a.recs, sizeof(uint2) * a.group_stride * groups) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
+           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
+    for (auto &q : lc.set) {
+        ok = ok && dev(&q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
+           && dev(&q.d_status_in, sizeof(int32_t) * F) && dev(&q.abort_, sizeof(int32_t) * F)
+           && dev(&q.cnt, sizeof(FFV2SymRec) * nb * F) && dev(&q.bits, sizeof(uint32_t) * nb * F)
+           && dev(&q.rowbase, sizeof(uint32_t) * 13 * (nb + 1) * F) && dev(&q.gbase, sizeof(uint32_t) * (nb + 1) * F)
+           && dev(&q.rawbase, sizeof(uint32_t) * (nb + 1) * F) && dev(&q.delta, sizeof(uint32_t) * 13 * nb * F)
+           && dev(&q.rows, a.row_stride * F) && dev(&q.raw, sizeof(uint32_t) * a.raw_words * F)
+           && dev(&q.packets, a.packet_stride * F) && dev(&q.sizes, sizeof(uint32_t) * F) && dev(&q.status, sizeof(int32_t) * F);
+    }
     if (!ok) return FFV2AMD_ERR_NOMEM;
-    a.codes = lc.d_codes; a.status_in = lc.d_status_in; a.split = lc.d_split;
-    HIPCHK(hipHostMalloc(&lc.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&lc.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
+    a.split = lc.d_split;
+    for (auto &q : lc.set) {
+        HIPCHK(hipHostMalloc(&q.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&q.ev_front, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&lc.back, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&lc.copy, hipStreamNonBlocking));
     // the symbols that carry no data: "no split" of every superblock (ffv2enc.c:222; the CDF of
     // daala_entropy.h:140-161 advances by itself), the range-coded part of the header (ffv2enc.c:449)
     std::vector<uint2> split;
@@ -1182,10 +1203,16 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
 static void lanecoder_free(ffv2amd_encoder *e)
 {
     auto &lc = e->lc;
+    if (lc.back) { (void)hipStreamSynchronize(lc.back); (void)hipStreamDestroy(lc.back); }
+    if (lc.copy) { (void)hipStreamSynchronize(lc.copy); (void)hipStreamDestroy(lc.copy); }
     for (void *p : lc.allocs) (void)hipFree(p);
     lc.allocs.clear();
-    if (lc.h_sizes) (void)hipHostFree(lc.h_sizes);
-    if (lc.h_status) (void)hipHostFree(lc.h_status);
+    for (auto &q : lc.set) {
+        if (q.h_sizes) (void)hipHostFree(q.h_sizes);
+        if (q.h_status) (void)hipHostFree(q.h_status);
+        if (q.ev_front) (void)hipEventDestroy(q.ev_front);
+        if (q.ev_done) (void)hipEventDestroy(q.ev_done);
+    }
     lc = ffv2amd_encoder::LaneCoder{};
 }
 
@@ -1218,17 +1245,20 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e)
     if (!e) return 0;
     const ffv2amd_info &in = e->info;
     const size_t nb = (size_t)in.block_planes, nsb = (size_t)in.num_sb_x * in.num_sb_y;
-    return ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + (nb * 4097 + 255) / 256 * 256
-         + in.packet_cap_qp * 4 + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
+    const size_t shared = ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + in.packet_cap_qp * 2 + 256;
+    const size_t per_set = (nb * 4097 + 255) / 256 * 256 + in.packet_cap_qp * 2
+                         + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
+    return shared + 2 * per_set;
 }
 
-int ffv2amd_lanecoder_encode(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W,
-                             uint8_t *h_packets, size_t packet_stride, uint32_t *h_sizes, int32_t *h_status)
+int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W)
 {
-    if (!e || !d_frames || !h_packets || !h_sizes || !h_status || nframes < 1) return FFV2AMD_ERR_INVAL;
+    if (!e || !d_frames || nframes < 1) return FFV2AMD_ERR_INVAL;
     if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
     auto &lc = e->lc;
     if (nframes > lc.cap) return FFV2AMD_ERR_INVAL;
+    auto &q = lc.set[lc.sub & 1u];
+    if (q.busy) return FFV2AMD_ERR_AGAIN;                        // two calls already in flight
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const ffv2amd_info &in = e->info;
@@ -1240,6 +1270,9 @@ int ffv2amd_lanecoder_encode(ffv2amd_encoder *e, int nframes, const void *d_fram
     hipStream_t s = e->stream;
     FFV2LaneCoderArgs a = lc.a;
     a.qp = qp;
+    a.codes = q.d_codes; a.status_in = q.d_status_in; a.abort_ = q.abort_; a.cnt = q.cnt; a.bits = q.bits;
+    a.rowbase = q.rowbase; a.gbase = q.gbase; a.rawbase = q.rawbase; a.delta = q.delta; a.rows = q.rows; a.raw = q.raw;
+    a.packets = q.packets; a.sizes = q.sizes; a.status = q.status;
     {   // raw header: pix_fmt & 15, then Exp-Golomb(qp) (ffv2enc.c:449-450)
         const uint32_t v = (uint32_t)qp + 1u;
         const int nbits = 31 - __builtin_clz(v);
@@ -1248,36 +1281,67 @@ int ffv2amd_lanecoder_encode(ffv2amd_encoder *e, int nframes, const void *d_fram
         a.header_bits = ((uint32_t)in.pix_fmt & 15u) | (code << 4);
         a.header_nbits = 4u + 2u * (uint32_t)nbits + 1u;
     }
-    HIPCHK(hipMemsetAsync(lc.d_status_in, 0, sizeof(int32_t) * nframes, s));
-    HIPCHK(hipMemsetAsync(a.abort_, 0, sizeof(int32_t) * nframes, s));
-    HIPCHK(hipMemsetAsync(a.raw, 0, sizeof(uint32_t) * a.raw_words * (size_t)nframes, s));
+    // front: the encoder's stream
+    HIPCHK(hipMemsetAsync(q.d_status_in, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(q.abort_, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(hipMemsetAsync(q.raw, 0, sizeof(uint32_t) * a.raw_words * (size_t)nframes, s));
     for (int f0 = 0; f0 < nframes; f0 += (int)B) {
         const int n = nframes - f0 < (int)B ? nframes - f0 : (int)B;
         FFV2TStageArgs t{};
         t.g = e->geom; t.nframes = n; t.frames = (const uint8_t *)d_frames + (size_t)f0 * in.frame_stride;
-        t.coef = e->d_coef_ws; t.energy = nullptr; t.codes = lc.d_codes + (size_t)f0 * nb * FFV2_CODES_PER_BP;
+        t.coef = e->d_coef_ws; t.energy = nullptr; t.codes = q.d_codes + (size_t)f0 * nb * FFV2_CODES_PER_BP;
         t.bitcnt = e->d_bitoff; t.W = d_W ? d_W + (size_t)f0 * nb : nullptr;
-        t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = lc.d_status_in + f0;
+        t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = q.d_status_in + f0;
         HIPCHK(ffv2_launch_tstage(t, s));
         HIPCHK(ffv2_launch_pvq(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, s));
         a.f0 = f0;
         HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, s));
     }
-    HIPCHK(ffv2_launch_lc_back(a, nframes, s));
-    HIPCHK(hipMemcpyAsync(lc.h_sizes, a.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(lc.h_status, a.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (int f = 0; f < nframes; f++) {
-        h_status[f] = lc.h_status[f];
+    HIPCHK(hipEventRecord(q.ev_front, s));
+    // back: cdf, chain, packets.  One call's back runs at a time (its scratch exists once).
+    HIPCHK(hipStreamWaitEvent(lc.back, q.ev_front, 0));
+    HIPCHK(ffv2_launch_lc_back(a, nframes, lc.back));
+    HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
+    HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
+    HIPCHK(hipEventRecord(q.ev_done, lc.back));
+    q.nframes = nframes; q.busy = true;
+    lc.sub++;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_lanecoder_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t packet_stride, uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !h_packets || !h_sizes || !h_status) return FFV2AMD_ERR_INVAL;
+    auto &lc = e->lc;
+    if (lc.fin == lc.sub) return FFV2AMD_ERR_AGAIN;              // nothing submitted
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &q = lc.set[lc.fin & 1u];
+    HIPCHK(hipEventSynchronize(q.ev_done));
+    // each packet with its own size, on the copy stream: the back stream may already hold the next call
+    for (int f = 0; f < q.nframes; f++) {
+        h_status[f] = q.h_status[f];
         h_sizes[f] = 0;
         if (h_status[f] < 0) continue;
-        if (lc.h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
-        h_sizes[f] = lc.h_sizes[f];
-        HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, a.packets + (size_t)f * a.packet_stride, h_sizes[f],
-                              hipMemcpyDeviceToHost, s));
+        if (q.h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
+        h_sizes[f] = q.h_sizes[f];
+        HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, q.packets + (size_t)f * lc.a.packet_stride, h_sizes[f],
+                              hipMemcpyDeviceToHost, lc.copy));
     }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(lc.copy));
+    q.busy = false;
+    lc.fin++;
     return FFV2AMD_OK;
+}
+
+int ffv2amd_lanecoder_encode(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W,
+                             uint8_t *h_packets, size_t packet_stride, uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !h_packets || !h_sizes || !h_status) return FFV2AMD_ERR_INVAL;
+    if (e->lc.fin != e->lc.sub) return FFV2AMD_ERR_INVAL;        // a submitted call is still waiting for its finish
+    const int r = ffv2amd_lanecoder_submit(e, nframes, d_frames, qp, d_W);
+    if (r < 0) return r;
+    return ffv2amd_lanecoder_finish(e, h_packets, packet_stride, h_sizes, h_status);
 }
 
 static int qp_alloc(ffv2amd_encoder *e)

@@ -204,20 +204,7 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
         const uint32_t nwords = (pos + 31u) >> 5, w0 = bit0 >> 5;
         if ((uint32_t)lane < nwords && sink[lane] && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
     }
-    // the symbols that carry no data: header, one "no split" per superblock, the padding of the last piece
-    if (lane == 0) {
-        if (bp % a.planes == 0) *lc_record(a.recs, a.group_stride, a.width, f, gb - 1) = a.split[bp / a.planes];
-        if (bp == 0) {
-            *lc_record(a.recs, a.group_stride, a.width, f, 0) = a.header;
-            atomicOr(&raw[0], a.header_bits);
-        }
-    }
-    if (bp == nb - 1) {
-        const uint32_t nsym = a.gbase[(size_t)f * (nb + 1) + nb];
-        const uint32_t k = nsym + (uint32_t)lane;
-        if (lane < 16 && k < ((nsym + 15u) & ~15u))
-            *lc_record(a.recs, a.group_stride, a.width, f, k) = make_uint2(0x80000000u, 0x8000u);   // fl 0, fh = ft = 32768
-    }
+    if (lane == 0 && bp == 0) atomicOr(&raw[0], a.header_bits);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,6 +228,16 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     uint32_t k0 = 0, bp_cur = 0;
     uint32_t seg_end = rowbase[1], dl_cur = delta[0];      // end of the current block-plane's band in this row, its delta
     uint2 *recs = lc_record(a.recs, a.group_stride, a.width, f, 0);   // this frame's slot 0 of piece 0
+    auto put = [&](uint32_t gp, uint2 r) { recs[((size_t)(gp >> 3) * (size_t)a.width) * 8 + (gp & 7u)] = r; };
+    if (b == 0) {
+        // the symbols that carry no data: header, one "no split" per superblock (in front of its first
+        // plane's symbols), the padding of the last tile with symbols of probability one
+        const uint32_t *gbase = a.gbase + (size_t)f * (nb + 1);
+        if (lane == 0) put(0, a.header);
+        for (int sb = lane; sb * a.planes < nb; sb += 64) put(gbase[sb * a.planes] - 1u, a.split[sb]);
+        const uint32_t nsym = gbase[nb], k = nsym + (uint32_t)lane;
+        if (lane < 16 && k < ((nsym + 15u) & ~15u)) put(k, make_uint2(0x80000000u, 0x8000u));   // fl 0, fh = ft = 32768
+    }
     auto chunk_len = [&](uint32_t F, uint32_t k, bool *halve) {
         // symbols until (and including) the one whose update halves the row (daala_entropy.c:434)
         const uint32_t th = F + 64u > 32767u ? 0u : (32768u - 64u - F + 63u) >> 6;
@@ -310,7 +307,7 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
             if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
             else {
                 const uint32_t gp = k0 + (uint32_t)lane + dl;
-                recs[((size_t)(gp >> 3) * (size_t)a.width) * 8 + (gp & 7u)] = make_uint2(fl | (fh << 16), ft);
+                put(gp, make_uint2(fl | (fh << 16), ft));
             }
         }
 

@@ -211,6 +211,34 @@ class FFV2Encoder:
                 raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
         return [pk[f, : sizes[f]].tobytes() for f in range(F)]
 
+    def lanecoder_submit(self, d_frames, qp, d_W=None):
+        """Asynchronous half of lanecoder_encode.  False when two calls are already in flight.  The
+        frames must stay alive and untouched until the matching lanecoder_finish()."""
+        r = self._lib.ffv2amd_lanecoder_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
+                                               d_W.data_ptr() if d_W is not None else None)
+        if r == -11:
+            return False
+        _lib.check(r, "ffv2amd_lanecoder_submit")
+        self._lc_pending = getattr(self, "_lc_pending", []) + [(d_frames, d_W)]
+        return True
+
+    def lanecoder_finish(self, packet_stride=None):
+        """Packets of the oldest submitted call: (packets[F, stride] uint8, sizes, status)."""
+        d_frames, _ = self._lc_pending.pop(0)
+        F = d_frames.shape[0]
+        cap = int(packet_stride or self.info.packet_cap_qp)
+        bufs = getattr(self, "_lc_bufs", {})
+        if (F, cap) not in bufs:
+            bufs[(F, cap)] = np.empty((F, cap), np.uint8)
+            self._lc_bufs = bufs
+        pk = bufs[(F, cap)]
+        sizes = np.zeros(F, np.uint32)
+        status = np.zeros(F, np.int32)
+        _lib.check(self._lib.ffv2amd_lanecoder_finish(self._h, pk.ctypes.data_as(C.c_void_p), cap,
+                                                      sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)),
+                   "ffv2amd_lanecoder_finish")
+        return pk, sizes, status
+
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
         r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,

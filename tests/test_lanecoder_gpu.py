@@ -136,3 +136,31 @@ def test_lanecoder_random_geometries_against_host_coder():
             checked += 1
         enc.close()
     assert checked > 40 and aborted > 0
+
+
+def test_lanecoder_two_calls_in_flight(oracle):
+    """submit(n+1) before finish(n): the front of call n+1 (own buffers) runs beside the chain of call n;
+    a third submit is refused; packets come back per call, identical to the synchronous path."""
+    W, H, fmt, P, depth, qp = 200, 130, "yuv444p", 3, 8, 16
+    enc = _enc(W, H, fmt, 2)
+    calls = [np.stack([synth.noise(100 * c + i, P, H, W, depth) for i in range(5 - c)]) for c in range(3)]
+    dev = [enc.upload(c) for c in calls]
+    enc.lanecoder_open(5)
+    want = []
+    for c in range(3):
+        pk, sizes, status = enc.lanecoder_encode(dev[c], qp, as_arrays=True)
+        assert not status.any()
+        want.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))])
+    assert want[0][0] == oracle.encode(calls[0][0], fmt, qp=qp)
+    assert enc.lanecoder_submit(dev[0], qp) and enc.lanecoder_submit(dev[1], qp)
+    assert not enc.lanecoder_submit(dev[2], qp)         # two in flight already: EAGAIN
+    got = []
+    pk, sizes, status = enc.lanecoder_finish()
+    got.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[0]))])
+    assert enc.lanecoder_submit(dev[2], qp)
+    for c in (1, 2):
+        pk, sizes, status = enc.lanecoder_finish()
+        assert not status.any()
+        got.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))])
+    assert got == want
+    enc.close()

@@ -323,29 +323,50 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
 // ---------------------------------------------------------------------------------------------
 // chain: lane = frame
 // ---------------------------------------------------------------------------------------------
-// State of one frame's chain: the range, and where the next symbol's offset lands: bit `o` of
-// word `woff` (the depth of the next symbol is 16 woff + 1 - o).  `acc` is that word so far.
-struct LcChain {
-    uint32_t rng, o, acc, woff;
+// One workgroup = two wavefronts over the same 64 frames (lane = frame).  A lone wavefront issues a
+// vector instruction only every ~6.5 cycles, dependent or not, so the step is split by what the
+// next symbol needs: wavefront 0 runs the range recurrence alone (rng -> u, d, next rng) and hands
+// (u, d) of every symbol to wavefront 1 through a ring of tiles in LDS; wavefront 1 (another SIMD
+// of the CU) turns them into the code words.  Neither ever waits for the other in steady state:
+// the consumer's step is half the producer's.
+#define LC_RING 8                          // tiles of 16 symbols x 64 lanes x 4 bytes in the ring
+
+typedef unsigned short lc_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t lc_recur(uint32_t &rng, uint32_t lo, uint32_t ft)
+{
+    // daala_entropy.c:362-378 with as few instructions as I could find (a lone wavefront pays ~6.5
+    // cycles for each, dependent or not).  The reference scales fl, fh, ft by two when
+    // rng - ft >= ft; with t = rng - ft and x = t - ft that is x >= 0 and then d = rng - 2 ft = x,
+    // else d = t: d = min(t, x) as unsigned numbers.  g = sat(2 d - ft') with ft' = rng - d is
+    // sat(3 d - rng).  Scaling needs ft < 32768, so fh << 1 < 65536 and both halves of `lo` shift in
+    // one go; the maps of fl and fh then run as one packed 16-bit computation (every term is at
+    // most rng < 65536).
+    const uint32_t t = rng - ft, x = t - ft;
+    const uint32_t d = t < x ? t : x;
+    const uint32_t g = __builtin_elementwise_sub_sat(3u * d, rng);
+    const uint32_t los = lo << (1u - (x >> 31));
+    const lc_us2 P = __builtin_bit_cast(lc_us2, los);
+    const lc_us2 G = { (unsigned short)g, (unsigned short)g }, D = { (unsigned short)d, (unsigned short)d };
+    const lc_us2 B = __builtin_elementwise_sub_sat(P, G) >> (lc_us2){ 1, 1 };
+    const lc_us2 U = P + __builtin_elementwise_min(P, G) + __builtin_elementwise_min(B, D);
+    const uint32_t u = U.x, r = (uint32_t)U.y - u;                    // 1 <= r < 65536
+    const uint32_t dd = (uint32_t)__builtin_clz(r) - 16u;              // 16 - ilog(r), :107-151
+    rng = r << dd;
+    return u | (dd << 16);                                             // u <= rng < 65536
+}
+
+// State of one frame's code: where the next symbol's offset lands: bit `o` of word `woff` (the
+// depth of the next symbol is 16 woff + 1 - o).  `acc` is that word so far.
+struct LcWords {
+    uint32_t o, acc, woff;
 };
 
-__device__ __forceinline__ void lc_step(LcChain &s, uint32_t lo, uint32_t ft, uint32_t *words)
+__device__ __forceinline__ void lc_word(LcWords &s, uint32_t ud, uint32_t *words)
 {
-    // daala_entropy.c:362-378.  Scaling by two (sc) needs rng >= 2 ft, hence ft < 32768 and
-    // fh << 1 < 65536: both halves of `lo` shift in one go.
-    const uint32_t sc = (s.rng - ft) >= ft ? 1u : 0u;
-    lo <<= sc; ft <<= sc;
-    const uint32_t fl = lo & 0xFFFFu, fh = lo >> 16;
-    const uint32_t d = s.rng - ft;
-    const uint32_t g = __builtin_elementwise_sub_sat(2u * d, ft);
-    const uint32_t bl = __builtin_elementwise_sub_sat(fl, g) >> 1, bh = __builtin_elementwise_sub_sat(fh, g) >> 1;
-    const uint32_t u = fl + (fl < g ? fl : g) + (bl < d ? bl : d);
-    const uint32_t v = fh + (fh < g ? fh : g) + (bh < d ? bh : d);
-    const uint32_t r = v - u;                                          // 1 <= r < 65536
-    const uint32_t dd = (uint32_t)__builtin_clz(r) - 16u;              // 16 - ilog(r), :107-151
-    s.rng = r << dd;
     // the word is stored every time; its last store stands.  A symbol shifts by <= 15 bits, so the
     // position moves on by at most one word.
+    const uint32_t u = ud & 0xFFFFu, dd = ud >> 16;
     s.acc += u << s.o;
     words[s.woff] = s.acc;
     const int o2 = (int)s.o - (int)dd;
@@ -355,9 +376,11 @@ __device__ __forceinline__ void lc_step(LcChain &s, uint32_t lo, uint32_t ft, ui
     s.o = (uint32_t)o2 & 15u;
 }
 
-__global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a, int nframes)
+__global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a, int nframes)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    __shared__ uint32_t ring[LC_RING * 16 * 64];
+    __shared__ uint32_t produced, consumed, final_rng[64];
+    const int g = blockIdx.x, lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int f = g * a.width + lane;
     const bool live = lane < a.width && f < nframes;
     uint32_t nsym = 0;
@@ -366,40 +389,81 @@ __global__ __launch_bounds__(64) void lc_chain_kernel(const FFV2LaneCoderArgs a,
     uint32_t maxt = ntiles;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)maxt, o, 64); maxt = t > maxt ? t : maxt; }
-    const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)g * a.group_stride) + (size_t)(live ? lane : 0) * 4;
-    const size_t piece = (size_t)a.width * 4;                          // uint4 per piece row (64 bytes per lane)
+    if (threadIdx.x == 0) { produced = 0; consumed = 0; }
+    __syncthreads();
+    // the two tile counters: relaxed workgroup-scope LDS accesses, ordered against the ring by hand
+    // (LDS serves a wavefront's instructions in order; a fence would also wait for the global loads
+    // and stores in flight, which is exactly what the prefetch and the word stores must not do)
+    auto peek = [](uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto post = [](uint32_t *p, uint32_t v) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     uint32_t *words = a.words + (size_t)(live ? f : 0) * a.wcap;
     const uint32_t wlimit = a.wcap - 2u;                               // a frame that runs past its words is refused by lc_finish_kernel
-    LcChain s{ 0x8000u, 1u, 0u, 0u };
-    uint4 buf[2][8];
-    if (maxt > 0 && 0 < ntiles) {
+    LcWords s{ 1u, 0u, 0u };
+
+    if (role == 0) {
+        // ---- the recurrence ----
+        const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)g * a.group_stride) + (size_t)(live ? lane : 0) * 4;
+        const size_t piece = (size_t)a.width * 4;                      // uint4 per piece row (64 bytes per lane)
+        uint32_t rng = 0x8000u;
+        // records two tiles ahead of the one being worked on (a tile is ~2 500 cycles of recurrence)
+        uint4 buf[3][8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) buf[0][i] = base[(size_t)(i >> 2) * piece + (i & 3)];
-    }
-    for (uint32_t t = 0; t < maxt; t += 2) {
+        for (int p = 0; p < 2; p++) {
+            if ((uint32_t)p < ntiles) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t tt = t + h;
-            if (tt + 1 < ntiles) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) buf[h ^ 1][i] = base[((size_t)(tt + 1) * 2 + (i >> 2)) * piece + (i & 3)];
-            }
-            if (tt < ntiles) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    lc_step(s, buf[h][i].x, buf[h][i].y, words);
-                    lc_step(s, buf[h][i].z, buf[h][i].w, words);
-                }
-                s.woff = s.woff < wlimit ? s.woff : wlimit;            // 16 symbols move on by <= 15 words: wcap has that slack
+                for (int i = 0; i < 8; i++) buf[p][i] = base[((size_t)p * 2 + (i >> 2)) * piece + (i & 3)];
             }
         }
+        for (uint32_t t = 0; t < maxt; t += 3) {
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                const uint32_t tt = t + h;
+                if (tt >= maxt) break;
+                if (tt + 2 < ntiles) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) buf[(h + 2) % 3][i] = base[((size_t)(tt + 2) * 2 + (i >> 2)) * piece + (i & 3)];
+                }
+                while (tt - peek(&consumed) >= (uint32_t)LC_RING) __builtin_amdgcn_s_sleep(2);      // ring full
+                asm volatile("" ::: "memory");
+                uint32_t *slot = ring + (tt % LC_RING) * (16 * 64) + lane;
+                if (tt < ntiles) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        slot[(2 * i) * 64] = lc_recur(rng, buf[h][i].x, buf[h][i].y);
+                        slot[(2 * i + 1) * 64] = lc_recur(rng, buf[h][i].z, buf[h][i].w);
+                    }
+                }
+                if (lane == 0) post(&produced, tt + 1u);
+            }
+        }
+        final_rng[lane] = rng;
+    } else {
+        // ---- the code words ----
+        for (uint32_t tt = 0; tt < maxt; tt++) {
+            while (peek(&produced) <= tt) __builtin_amdgcn_s_sleep(2);     // tile not there yet
+            asm volatile("" ::: "memory");
+            const uint32_t *slot = ring + (tt % LC_RING) * (16 * 64) + lane;
+            if (tt < ntiles) {
+                uint32_t ud[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) ud[i] = slot[i * 64];
+#pragma unroll
+                for (int i = 0; i < 16; i++) lc_word(s, ud[i], words);
+                s.woff = s.woff < wlimit ? s.woff : wlimit;            // 16 symbols move on by <= 15 words: wcap has that slack
+            }
+            if (lane == 0) post(&consumed, tt + 1u);
+        }
     }
-    if (live) {
+    __syncthreads();                                                   // final_rng
+    if (role == 1 && live) {
         // the word the next symbol would go to, and a clear one behind it
         words[s.woff] = s.acc;
         words[s.woff + 1] = 0;
         FFV2LaneState st;
-        st.woff = s.woff; st.o = s.o; st.rng = s.rng; st.full = s.woff >= wlimit ? 1u : 0u;
+        st.woff = s.woff; st.o = s.o; st.rng = final_rng[lane]; st.full = s.woff >= wlimit ? 1u : 0u;
         a.state[f] = st;
     }
 }
@@ -517,7 +581,7 @@ hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, in
 hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s)
 {
     hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(64), 0, s, a, nframes);
+    hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(128), 0, s, a, nframes);
     hipLaunchKernelGGL(lc_finish_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -16,8 +16,9 @@
 //            (daala_entropy.c:428-440), never with the range: between two halvings a row is its
 //            value at the last halving plus 64 x a prefix count, so 64 symbols at a time get
 //            their (fl, fh, ft) from ballots; written as records in coding order.
-//   chain    per 64 frames, lane = frame: the interval update (daala_entropy.c:362-378) and the
-//            renormalisation shift (:107-151) -- the only serial part.  `low` is not carried:
+//   chain    per 64 frames, lane = frame, two wavefronts: the interval update (daala_entropy.c:362-378)
+//            and the renormalisation shift (:107-151) -- the only serial part -- on one, the code
+//            words on the other, a ring of tiles in LDS between them.  `low` is not carried:
 //            the code is sum_k u_k << (T - D_k) (D_k = shifts before symbol k), accumulated into
 //            32-bit words anchored every 16 bits of depth; a symbol shifts by <= 15 bits, so the
 //            anchor advances by 0 or 1 per symbol.

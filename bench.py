@@ -104,7 +104,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     d = enc.upload(host_frames)
     d_frames = d.repeat((F + distinct - 1) // distinct, *([1] * (d.dim() - 1)))[:F].contiguous()
     del d
-    enc.lanecoder_open(F)
+    enc.lanecoder_open(F, args.packet_cap)
     pk, sizes, status = enc.lanecoder_encode(d_frames, args.qp, as_arrays=True)
     stride = int(sizes.max()) * 5 // 4 + 4096          # host packet pitch for the timed calls
     for _ in range(args.warmup):
@@ -134,7 +134,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                                       "frames resident in HBM, packets to host memory" % (W, H, fmt, args.qp, F, distinct),
                           "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
                           "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
-                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame() / 1e9, 1)},
+                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap) / 1e9, 1),
+                          "packet_cap": args.packet_cap or enc.info.packet_cap_qp},
                "roofline": None}
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
@@ -183,6 +184,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="with --qp: the many-frames-in-flight device coder (ffv2_lanecoder.hip, one frame per lane of the "
                          "range chain); a step is one call over this many device-resident frames")
+    ap.add_argument("--packet-cap", type=int, default=0,
+                    help="with --frames-in-flight: bytes of HBM reserved per packet (0 = the encoder's bound for any qp)")
     ap.add_argument("--qp", type=int, default=0,
                     help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()

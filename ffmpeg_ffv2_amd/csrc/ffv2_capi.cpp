@@ -1136,7 +1136,7 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
 // submit(n+1) before finish(n) runs the front of call n+1 beside the chain of call n, which keeps
 // only 1/16 of the chip's SIMDs busy.
 // ------------------------------------------------------------------
-static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
+static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
 {
     auto &lc = e->lc;
     const ffv2amd_info &in = e->info;
@@ -1155,9 +1155,9 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames)
     const size_t maxsym = ((1 + nsb + nb * 4097) + 15) / 16 * 16;
     a.group_stride = maxsym * (size_t)width;                       // uint2 per group
     a.row_stride = (nb * 4097 + 255) / 256 * 256;
-    a.raw_words = (uint32_t)(in.packet_cap_qp / 4 + 4);
-    a.wcap = (uint32_t)(in.packet_cap_qp / 2 + 32);
-    a.packet_stride = in.packet_cap_qp;
+    a.raw_words = (uint32_t)(pcap / 4 + 4);
+    a.wcap = (uint32_t)(pcap / 2 + 32);
+    a.packet_stride = pcap;
     bool ok = dev(&a.recs, sizeof(uint2) * a.group_stride * groups) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
            && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
     for (auto &q : lc.set) {
@@ -1216,16 +1216,19 @@ static void lanecoder_free(ffv2amd_encoder *e)
     lc = ffv2amd_encoder::LaneCoder{};
 }
 
-int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight)
+int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t packet_cap)
 {
     if (!e || frames_in_flight < 1 || frames_in_flight > (1 << 20)) return FFV2AMD_ERR_INVAL;
+    if (packet_cap == 0 || packet_cap > e->info.packet_cap_qp) packet_cap = e->info.packet_cap_qp;
+    if (packet_cap < 64) return FFV2AMD_ERR_INVAL;
+    packet_cap = (packet_cap + 15) / 16 * 16;
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     if (e->lc.cap) {
         HIPCHK(hipStreamSynchronize(e->stream));
         lanecoder_free(e);
     }
-    const int r = lanecoder_alloc(e, frames_in_flight);
+    const int r = lanecoder_alloc(e, frames_in_flight, packet_cap);
     if (r < 0) lanecoder_free(e);
     return r;
 }
@@ -1240,13 +1243,14 @@ int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
     return FFV2AMD_OK;
 }
 
-size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e)
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet_cap)
 {
     if (!e) return 0;
     const ffv2amd_info &in = e->info;
+    if (packet_cap == 0 || packet_cap > in.packet_cap_qp) packet_cap = in.packet_cap_qp;
     const size_t nb = (size_t)in.block_planes, nsb = (size_t)in.num_sb_x * in.num_sb_y;
-    const size_t shared = ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + in.packet_cap_qp * 2 + 256;
-    const size_t per_set = (nb * 4097 + 255) / 256 * 256 + in.packet_cap_qp * 2
+    const size_t shared = ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + packet_cap * 2 + 256;
+    const size_t per_set = (nb * 4097 + 255) / 256 * 256 + packet_cap * 2
                          + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
     return shared + 2 * per_set;
 }

@@ -166,7 +166,11 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  * kernels bound it; a call takes at least one frame's chain (about 75 ns per symbol).
  *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call
  *                      (ffv2amd_lanecoder_bytes_per_frame() each: 84 MB per 1080p frame);
- *                      FFV2AMD_ERR_NOMEM if the device cannot hold it.
+ *                      FFV2AMD_ERR_NOMEM if the device cannot hold it.  packet_cap = 0 reserves
+ *                      ffv2amd_info.packet_cap_qp bytes per packet (2 100 per block-plane, six
+ *                      buffers of that size per frame); a smaller packet_cap saves HBM, and a frame
+ *                      whose packet would not fit comes back as FFV2AMD_ERR_NOSPACE (noise at
+ *                      qp 16 / 64 codes to 160 / 370 bytes per block-plane).
  *   lanecoder_submit : up to that many device-resident frames (layout of ffv2amd_info), qp 1..64.
  *                      Asynchronous; the frames (and W) stay untouched until the call's finish.
  *                      Two calls may be in flight (FFV2AMD_ERR_AGAIN for a third): the transform,
@@ -177,9 +181,9 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  *                      (FFV2AMD_ERR_ABORT where the reference would av_assert0).
  *   lanecoder_encode : submit + finish.
  * One thread drives a coder.  PARITY UNPINNED like all of qp > 0. */
-int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight);
+int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap);
 int    ffv2amd_lanecoder_close(ffv2amd_encoder *enc);
-size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc);
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc, size_t packet_cap);
 int    ffv2amd_lanecoder_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int    ffv2amd_lanecoder_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

@@ -164,3 +164,25 @@ def test_lanecoder_two_calls_in_flight(oracle):
         got.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))])
     assert got == want
     enc.close()
+
+
+def test_lanecoder_small_packet_cap_reports_nospace(oracle):
+    """A tight packet_cap saves HBM; a frame that does not fit is refused, the others are unaffected."""
+    W, H, fmt, P, depth, qp = 128, 128, "gray", 1, 8, 16
+    enc = _enc(W, H, fmt, 2)
+    quiet = np.full((P, H, W), 128, np.uint8)
+    quiet[:, :64, :64] = synth.noise(2, P, 64, 64, depth)          # one busy block, three flat ones
+    frames = np.stack([synth.noise(1, P, H, W, depth), quiet])
+    want = [oracle.encode(f, fmt, qp=qp) for f in frames]
+    assert len(want[0]) > len(want[1]) + 32                # 670 and 623 bytes
+    cap = len(want[1]) + 20                                # rounded up to 16 inside: still short of frame 0
+    dev = enc.upload(frames)
+    enc.lanecoder_open(2, packet_cap=cap)
+    assert enc.lanecoder_bytes_per_frame(cap) < enc.lanecoder_bytes_per_frame()
+    pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+    assert status[0] == -28 and status[1] == 0
+    assert pk[1, : sizes[1]].tobytes() == want[1]
+    enc.lanecoder_open(2)                              # reopen with the default bound
+    pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+    assert [pk[i, : sizes[i]].tobytes() for i in range(2)] == want
+    enc.close()

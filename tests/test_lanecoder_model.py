@@ -36,3 +36,18 @@ def test_neutral_symbol_is_a_no_op_for_every_range():
     for rng in range(32768, 65536, 97):
         u, r = M.interval(rng, 0, 32768, 32768)
         assert (u, r) == (0, rng)
+
+
+def test_kernel_form_of_the_interval_update_equals_the_reference_form():
+    """lc_recur's algebra (d = min(t, x), g = sat(3 d - rng), packed 16-bit maps) against the interval
+    update as daala_entropy.c:362-378 writes it, over the whole range of rng and random CDF triples
+    with 16384 < ft <= 32768 (what `ft << sc` of daala_entropy.c:346 yields), including ft = 32768."""
+    import random
+    rnd = random.Random(5)
+    for rng in list(range(32768, 65536, 61)) + [32768, 65535]:
+        for _ in range(40):
+            ft = rnd.choice([16385, 32768, rnd.randint(16385, 32768)])
+            fh = rnd.randint(1, ft)
+            fl = rnd.randint(0, fh - 1)
+            assert M.interval_kernel(rng, fl, fh, ft) == M.interval(rng, fl, fh, ft), (rng, fl, fh, ft)
+        assert M.interval_kernel(rng, 0, 32768, 32768) == (0, rng)

@@ -38,6 +38,25 @@ def interval(rng, fl, fh, ft):
     return u, v - u
 
 
+def interval_kernel(rng, fl, fh, ft):
+    """the same interval as lc_recur computes it (ffv2_lanecoder.hip): unsigned 32-bit min instead of
+    the compare, g from 3 d - rng, both bounds in 16-bit halves of one word"""
+    M = 0xFFFFFFFF
+    t = (rng - ft) & M
+    x = (t - ft) & M
+    d = min(t, x)
+    g = max(3 * d - rng, 0)
+    sc = 1 - (x >> 31)
+    lo = ((fl | (fh << 16)) << sc) & M
+    out = []
+    for h in (lo & 0xFFFF, lo >> 16):
+        b = max(h - g, 0) >> 1
+        v = h + min(h, g) + min(b, d)
+        assert v < 65536 and g < 65536 and d < 65536, "the packed 16-bit lanes must not overflow"
+        out.append(v)
+    return out[0], out[1] - out[0]
+
+
 class DirectCoder:
     """the coder as the reference runs it: 64-bit window, 16-bit pre-carry words"""
 

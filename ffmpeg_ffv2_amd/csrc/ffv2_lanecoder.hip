@@ -248,14 +248,19 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     };
     bool halve = false;
     uint32_t m = k0 < L ? chunk_len(F0, k0, &halve) : 0u;
-    uint32_t x = (uint32_t)lane < m ? src[k0 + lane] : 255u;
+    // symbols are loaded unconditionally (address clamped to the row) and masked when used: a
+    // load under a lane mask makes the compiler wait for it on the spot
+    const uint32_t last = L ? L - 1u : 0u;
+    uint32_t xr = src[(uint32_t)lane < last ? (uint32_t)lane : last];
     while (k0 < L) {
         // the next chunk's symbols are on their way while this one is worked on
         const uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
         const uint32_t k1 = k0 + m;
         bool halve1 = false;
         const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
-        const uint32_t x1 = (uint32_t)lane < m1 ? src[k1 + lane] : 255u;
+        const uint32_t p1 = k1 + (uint32_t)lane;
+        const uint32_t xr1 = src[p1 < last ? p1 : last];
+        const uint32_t x = (uint32_t)lane < m ? xr : 255u;
 
         // prefix counts: cl / ch = symbols of this chunk in front of lane t with a value below / up
         // to lane t's own; ca (lane i as row entry i) = symbols of the chunk with value <= i.  One
@@ -308,7 +313,11 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
             if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
             else {
                 const uint32_t gp = k0 + (uint32_t)lane + dl;
+#if defined(LC_CDF_EXP) && LC_CDF_EXP == 1    // timing experiment: no record stores
+                if (gp == 0xFFFFFFFFu) put(gp, make_uint2(fl | (fh << 16), ft));
+#else
                 put(gp, make_uint2(fl | (fh << 16), ft));
+#endif
             }
         }
 
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         const uint32_t ge = lastx <= (uint32_t)lane ? 1u : 0u;
         if (halve) R = ((R + 64u * (ca - ge)) >> 1) + (uint32_t)lane + 1u + 64u * ge;
         else R += 64u * ca;
-        F0 = F1; k0 = k1; m = m1; halve = halve1; x = x1;
+        F0 = F1; k0 = k1; m = m1; halve = halve1; xr = xr1;
     }
 }
 

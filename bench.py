@@ -105,18 +105,26 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     d_frames = d.repeat((F + distinct - 1) // distinct, *([1] * (d.dim() - 1)))[:F].contiguous()
     del d
     enc.lanecoder_open(F, args.packet_cap)
-    pk, sizes, status = enc.lanecoder_encode(d_frames, args.qp, as_arrays=True)
-    stride = int(sizes.max()) * 5 // 4 + 4096          # host packet pitch for the timed calls
-    for _ in range(args.warmup):
-        enc.lanecoder_encode(d_frames, args.qp, packet_stride=stride, as_arrays=True)
+    def finish():
+        if not args.strided_packets:
+            return enc.lanecoder_finish_packed()
+        pk, sizes, status = enc.lanecoder_finish(packet_stride=stride)
+        return pk.reshape(-1), np.arange(F, dtype=np.uint64) * np.uint64(stride), sizes, status
+
+    enc.lanecoder_submit(d_frames, args.qp)
+    stride = int(enc.lanecoder_finish_packed()[2].max()) * 5 // 4 + 4096      # row pitch of the strided variant
+    for _ in range(max(args.warmup, 1)):
+        enc.lanecoder_submit(d_frames, args.qp)
+        finish()
     barrier()
-    # two calls in flight: the front of step i+1 (T-stage, PVQ, bookkeeping) runs beside the chain of step i
+    # two calls in flight: the front of step i+1 (T-stage, PVQ, bookkeeping) runs beside the chain of
+    # step i; the packets of a step come back packed, in one copy
     t0 = time.perf_counter()
     enc.lanecoder_submit(d_frames, args.qp)
     for i in range(args.steps):
         if i + 1 < args.steps:
             enc.lanecoder_submit(d_frames, args.qp)
-        pk, sizes, status = enc.lanecoder_finish(packet_stride=stride)
+        buf, offs, sizes, status = finish()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -135,7 +143,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                           "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
                           "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
                           "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap) / 1e9, 1),
-                          "packet_cap": args.packet_cap or enc.info.packet_cap_qp},
+                          "packet_cap": args.packet_cap or enc.info.packet_cap_qp,
+                          "packets_out": "one copy per packet" if args.strided_packets else "packed, one copy"},
                "roofline": None}
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
@@ -146,7 +155,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                 ref = oracle.encode(host_frames[n_done], fmt, qp=args.qp)
                 tcpu += time.perf_counter() - c0
                 for i in range(n_done, F, distinct):      # every repetition of this frame
-                    ok = ok and status[i] == 0 and pk[i, : sizes[i]].tobytes() == ref
+                    ok = ok and status[i] == 0 and buf[int(offs[i]): int(offs[i]) + int(sizes[i])].tobytes() == ref
                 n_done += 1
             res["cpu_baseline"] = {"value": round(n_done * W * H / tcpu / 1e6, 2), "unit": "Mpix/s", "cores": 1,
                                    "kind": "port", "sample": "%d of the %d distinct benchmark frames, oracle qp=%d, 1 thread"
@@ -184,6 +193,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="with --qp: the many-frames-in-flight device coder (ffv2_lanecoder.hip, one frame per lane of the "
                          "range chain); a step is one call over this many device-resident frames")
+    ap.add_argument("--strided-packets", action="store_true",
+                    help="with --frames-in-flight: packets come back one copy each into a [frames][stride] array "
+                         "(ffv2amd_lanecoder_finish) instead of packed in one copy (ffv2amd_lanecoder_finish_packed)")
     ap.add_argument("--packet-cap", type=int, default=0,
                     help="with --frames-in-flight: bytes of HBM reserved per packet (0 = the encoder's bound for any qp)")
     ap.add_argument("--qp", type=int, default=0,

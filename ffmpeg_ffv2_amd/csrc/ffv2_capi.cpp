@@ -572,6 +572,7 @@ struct ffv2amd_encoder {
             FFV2SymRec *cnt = nullptr;
             uint8_t *rows = nullptr, *packets = nullptr;
             uint32_t *raw = nullptr, *sizes = nullptr;
+            unsigned long long *offs = nullptr, *h_offs = nullptr;
             uint32_t *h_sizes = nullptr;
             int32_t *h_status = nullptr;
             hipEvent_t ev_front = nullptr, ev_done = nullptr;
@@ -1159,7 +1160,7 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
     a.wcap = (uint32_t)(pcap / 2 + 32);
     a.packet_stride = pcap;
     bool ok = dev(&a.recs, sizeof(uint2) * a.group_stride * groups) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
-           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
+           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.fin, sizeof(uint4) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
     for (auto &q : lc.set) {
         ok = ok && dev(&q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
            && dev(&q.d_status_in, sizeof(int32_t) * F) && dev(&q.abort_, sizeof(int32_t) * F)
@@ -1167,13 +1168,15 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
            && dev(&q.rowbase, sizeof(uint32_t) * 13 * (nb + 1) * F) && dev(&q.gbase, sizeof(uint32_t) * (nb + 1) * F)
            && dev(&q.rawbase, sizeof(uint32_t) * (nb + 1) * F) && dev(&q.delta, sizeof(uint32_t) * 13 * nb * F)
            && dev(&q.rows, a.row_stride * F) && dev(&q.raw, sizeof(uint32_t) * a.raw_words * F)
-           && dev(&q.packets, a.packet_stride * F) && dev(&q.sizes, sizeof(uint32_t) * F) && dev(&q.status, sizeof(int32_t) * F);
+           && dev(&q.packets, a.packet_stride * F) && dev(&q.sizes, sizeof(uint32_t) * F) && dev(&q.status, sizeof(int32_t) * F)
+           && dev(&q.offs, sizeof(unsigned long long) * (F + 1));
     }
     if (!ok) return FFV2AMD_ERR_NOMEM;
     a.split = lc.d_split;
     for (auto &q : lc.set) {
         HIPCHK(hipHostMalloc(&q.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&q.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_offs, sizeof(unsigned long long) * (F + 1), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&q.ev_front, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
     }
@@ -1210,6 +1213,7 @@ static void lanecoder_free(ffv2amd_encoder *e)
     for (auto &q : lc.set) {
         if (q.h_sizes) (void)hipHostFree(q.h_sizes);
         if (q.h_status) (void)hipHostFree(q.h_status);
+        if (q.h_offs) (void)hipHostFree(q.h_offs);
         if (q.ev_front) (void)hipEventDestroy(q.ev_front);
         if (q.ev_done) (void)hipEventDestroy(q.ev_done);
     }
@@ -1276,7 +1280,7 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     a.qp = qp;
     a.codes = q.d_codes; a.status_in = q.d_status_in; a.abort_ = q.abort_; a.cnt = q.cnt; a.bits = q.bits;
     a.rowbase = q.rowbase; a.gbase = q.gbase; a.rawbase = q.rawbase; a.delta = q.delta; a.rows = q.rows; a.raw = q.raw;
-    a.packets = q.packets; a.sizes = q.sizes; a.status = q.status;
+    a.packets = q.packets; a.sizes = q.sizes; a.status = q.status; a.offs = q.offs;
     {   // raw header: pix_fmt & 15, then Exp-Golomb(qp) (ffv2enc.c:449-450)
         const uint32_t v = (uint32_t)qp + 1u;
         const int nbits = 31 - __builtin_clz(v);
@@ -1307,6 +1311,7 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     HIPCHK(ffv2_launch_lc_back(a, nframes, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
+    HIPCHK(hipMemcpyAsync(q.h_offs, q.offs, sizeof(unsigned long long) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipEventRecord(q.ev_done, lc.back));
     q.nframes = nframes; q.busy = true;
     lc.sub++;
@@ -1322,15 +1327,43 @@ int ffv2amd_lanecoder_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t pack
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     auto &q = lc.set[lc.fin & 1u];
     HIPCHK(hipEventSynchronize(q.ev_done));
-    // each packet with its own size, on the copy stream: the back stream may already hold the next call
+    // packets on the copy stream (the back stream may already hold the next call): they lie packed
+    // on the device, each goes to its own row of the caller's array
     for (int f = 0; f < q.nframes; f++) {
         h_status[f] = q.h_status[f];
         h_sizes[f] = 0;
         if (h_status[f] < 0) continue;
         if (q.h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
         h_sizes[f] = q.h_sizes[f];
-        HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, q.packets + (size_t)f * lc.a.packet_stride, h_sizes[f],
+        HIPCHK(hipMemcpyAsync(h_packets + (size_t)f * packet_stride, q.packets + q.h_offs[f], h_sizes[f],
                               hipMemcpyDeviceToHost, lc.copy));
+    }
+    HIPCHK(hipStreamSynchronize(lc.copy));
+    q.busy = false;
+    lc.fin++;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *e, uint8_t *h_buf, size_t h_cap, uint64_t *h_offsets,
+                                    uint32_t *h_sizes, int32_t *h_status)
+{
+    if (!e || !h_buf || !h_offsets || !h_sizes || !h_status) return FFV2AMD_ERR_INVAL;
+    auto &lc = e->lc;
+    if (lc.fin == lc.sub) return FFV2AMD_ERR_AGAIN;              // nothing submitted
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &q = lc.set[lc.fin & 1u];
+    HIPCHK(hipEventSynchronize(q.ev_done));
+    const size_t total = (size_t)q.h_offs[q.nframes];
+    if (total > h_cap) return FFV2AMD_ERR_NOSPACE;               // the call stays queued: finish it with a larger buffer
+    // the packets lie packed on the device: one copy
+    static const size_t piece = getenv("FFV2AMD_LC_PIECE") ? (size_t)atol(getenv("FFV2AMD_LC_PIECE")) : ((size_t)4 << 20);
+    for (size_t from = 0; from < total; from += piece)            // in pieces: a single large copy crawls while kernels run
+        HIPCHK(hipMemcpyAsync(h_buf + from, q.packets + from, total - from < piece ? total - from : piece, hipMemcpyDeviceToHost, lc.copy));
+    for (int f = 0; f < q.nframes; f++) {
+        h_status[f] = q.h_status[f];
+        h_sizes[f] = h_status[f] < 0 ? 0u : q.h_sizes[f];
+        h_offsets[f] = q.h_offs[f];
     }
     HIPCHK(hipStreamSynchronize(lc.copy));
     q.busy = false;

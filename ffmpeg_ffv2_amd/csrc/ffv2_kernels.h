@@ -124,10 +124,12 @@ struct FFV2LaneCoderArgs {
     uint32_t *words;                  // [F][wcap] the range code as anchored 32-bit words
     uint32_t wcap;
     FFV2LaneState *state;             // [F]
-    uint8_t *packets;                 // [F][packet_stride]
-    size_t packet_stride;
+    uint8_t *packets;                 // packed: packet f at packets + offs[f] (16-byte aligned); capacity F * packet_stride
+    size_t packet_stride;             // most one packet may take
     uint32_t *sizes;                  // [F]
     int32_t *status;                  // [F]
+    unsigned long long *offs;         // [F + 1] packet offsets, [F] = bytes in all
+    uint4 *fin;                       // [F] range bytes, slack bits, bytes the carry chain covers
 };
 hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
 hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s);                      // cdf, chain, finish of frames 0..nframes-1

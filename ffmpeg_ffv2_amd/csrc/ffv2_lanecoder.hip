@@ -22,9 +22,10 @@
 //            the code is sum_k u_k << (T - D_k) (D_k = shifts before symbol k), accumulated into
 //            32-bit words anchored every 16 bits of depth; a symbol shifts by <= 15 bits, so the
 //            anchor advances by 0 or 1 per symbol.
-//   finish   per frame: ff_daalaent_encode_done's rounding (:624-674) as one more addend, the
-//            words to bytes through a one-bit carry look-ahead (:706-715), the raw bytes behind
-//            them in reverse order (:676-721).
+//   finish   per frame: ff_daalaent_encode_done's rounding (:624-674) as one more addend (size),
+//            a prefix sum over the packet sizes (offsets: the packets leave the device packed),
+//            the words to bytes through a one-bit carry look-ahead (:706-715) and the raw bytes
+//            behind them in reverse order (:676-721) (write).
 // PARITY UNPINNED, as all of qp > 0; tests hold this coder to the host coder's and
 // the oracle's packets.
 #include "ffv2_kernels.h"
@@ -488,61 +489,85 @@ __device__ __forceinline__ uint32_t lc_bytesum(const uint32_t *W, uint32_t i)
     return (i & 1u) ? (a & 255u) + ((b >> 16) & 255u) : ((a >> 8) & 255u) + (b >> 24);
 }
 
-__global__ __launch_bounds__(256) void lc_finish_kernel(const FFV2LaneCoderArgs a)
+// finish, step 1 (one wavefront per frame, lane 0 works): ff_daalaent_encode_done's rounding as one
+// more addend, the packet's size and status
+__global__ __launch_bounds__(64) void lc_size_kernel(const FFV2LaneCoderArgs a)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    uint32_t *W = a.words + (size_t)f * a.wcap;
+    int status = a.status_in[f] < 0 ? a.status_in[f] : (a.abort_[f] || a.qp < 2) ? -1 : 0;   // qp 1: ft = 1 < 2, daala_entropy.c:342
+    uint32_t nbytes = 0, slack = 0, top = 0, total = 0;
+    if (status == 0) {
+        const FFV2LaneState st = a.state[f];
+        const uint32_t wT = st.woff, oT = st.o, rng = st.rng;
+        const uint32_t T = 16u * wT + 1u - oT;                        // all shifts so far
+        const uint32_t npre = T >= 1u ? (T - 1u) >> 3 : 0u;
+        const int cnt = -9 + (int)(T - 8u * npre);
+        // the coder's window (the low cnt + 24 bits of the code so far) read back from the last words
+        unsigned long long V = W[wT];
+        if (wT >= 1) V += (unsigned long long)W[wT - 1] << 16;
+        if (wT >= 2) V += (unsigned long long)W[wT - 2] << 32;
+        const uint32_t low = (uint32_t)(V >> oT) & ((1u << (cnt + 24)) - 1u);
+        uint32_t m = 0x7FFF, e = (low + m) & ~m;                      // daala_entropy.c:624-674
+        int s = 9;
+        while ((e | m) >= low + rng) { s++; m >>= 1; e = (low + m) & ~m; }
+        s += cnt;
+        const uint32_t extra = s > 0 ? (uint32_t)(s + 7) >> 3 : 0u;
+        slack = s > 0 ? 8u * extra - (uint32_t)s : (uint32_t)(-s);
+        nbytes = npre + extra;
+        top = 2u * wT + 2u;
+        const uint32_t R = a.rawbase[(size_t)f * (a.nblk + 1) + a.nblk];
+        const uint32_t nraw = R > slack ? (R - slack + 7u) >> 3 : 0u;
+        total = nbytes + nraw;
+        const bool leftover = 8u * nraw < R;
+        if (st.full || total > a.packet_stride || (size_t)(R + 31u) / 32u > a.raw_words) status = -28;
+        else if (leftover && nbytes == 0) status = -1;                // daala_entropy.c:719
+        else W[wT] += (e - low) << oT;
+    }
+    a.status[f] = status;
+    a.sizes[f] = status < 0 ? 0u : total;
+    a.fin[f] = make_uint4(nbytes, slack, top, 0u);
+}
+
+// finish, step 2 (one workgroup): where every packet starts in the packed output (16-byte aligned)
+__global__ __launch_bounds__(256) void lc_offsets_kernel(const FFV2LaneCoderArgs a, int nframes)
+{
+    __shared__ unsigned long long part[256];
+    const int tid = threadIdx.x;
+    const int per = (nframes + 255) / 256, f0 = tid * per, f1 = f0 + per < nframes ? f0 + per : nframes;
+    unsigned long long sum = 0;
+    for (int f = f0; f < f1; f++) sum += (a.sizes[f] + 15u) & ~15u;
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 256; t++) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+        a.offs[nframes] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[tid];
+    for (int f = f0; f < f1; f++) { a.offs[f] = run; run += (a.sizes[f] + 15u) & ~15u; }
+}
+
+// finish, step 3 (one workgroup per frame): the words to bytes through a one-bit carry look-ahead
+// (daala_entropy.c:706-715), the raw bytes behind them in reverse order (:676-721)
+__global__ __launch_bounds__(256) void lc_write_kernel(const FFV2LaneCoderArgs a)
 {
     __shared__ uint32_t fn[256];
     __shared__ uint32_t cin[256];
-    __shared__ uint32_t sh_nbytes, sh_slack, sh_top;
-    __shared__ int sh_status;
     const int f = blockIdx.x, tid = threadIdx.x;
-    uint32_t *W = a.words + (size_t)f * a.wcap;
+    if (a.status[f] < 0) return;
+    const uint32_t *W = a.words + (size_t)f * a.wcap;
     const uint32_t *raw = a.raw + (size_t)f * a.raw_words;
-    uint8_t *pkt = a.packets + (size_t)f * a.packet_stride;
-    if (tid == 0) {
-        int status = a.status_in[f] < 0 ? a.status_in[f] : (a.abort_[f] || a.qp < 2) ? -1 : 0;   // qp 1: ft = 1 < 2, daala_entropy.c:342
-        uint32_t nbytes = 0, slack = 0, top = 0;
-        if (status == 0) {
-            const FFV2LaneState st = a.state[f];
-            const uint32_t wT = st.woff, oT = st.o, rng = st.rng;
-            const uint32_t T = 16u * wT + 1u - oT;                    // all shifts so far
-            const uint32_t npre = T >= 1u ? (T - 1u) >> 3 : 0u;
-            const int cnt = -9 + (int)(T - 8u * npre);
-            // the coder's window (the low cnt + 24 bits of the code so far) read back from the last words
-            unsigned long long V = W[wT];
-            if (wT >= 1) V += (unsigned long long)W[wT - 1] << 16;
-            if (wT >= 2) V += (unsigned long long)W[wT - 2] << 32;
-            const uint32_t low = (uint32_t)(V >> oT) & ((1u << (cnt + 24)) - 1u);
-            uint32_t m = 0x7FFF, e = (low + m) & ~m;                  // daala_entropy.c:624-674
-            int s = 9;
-            while ((e | m) >= low + rng) { s++; m >>= 1; e = (low + m) & ~m; }
-            s += cnt;
-            const uint32_t extra = s > 0 ? (uint32_t)(s + 7) >> 3 : 0u;
-            slack = s > 0 ? 8u * extra - (uint32_t)s : (uint32_t)(-s);
-            nbytes = npre + extra;
-            top = 2u * wT + 2u;
-            if (st.full) status = -28;
-            else W[wT] += (e - low) << oT;
-        }
-        sh_status = status; sh_nbytes = nbytes; sh_slack = slack; sh_top = top;
-    }
-    __syncthreads();
-    __threadfence_block();
-    const int status = sh_status;
-    if (status < 0) {
-        if (tid == 0) { a.status[f] = status; a.sizes[f] = 0; }
-        return;
-    }
-    const uint32_t nbytes = sh_nbytes, slack = sh_slack, top = sh_top;
+    uint8_t *pkt = a.packets + a.offs[f];
+    const uint4 fin = a.fin[f];
+    const uint32_t nbytes = fin.x, slack = fin.y, top = fin.z, total = a.sizes[f];
     const uint32_t R = a.rawbase[(size_t)f * (a.nblk + 1) + a.nblk];
     const uint32_t nraw = R > slack ? (R - slack + 7u) >> 3 : 0u;
-    const uint32_t total = nbytes + nraw;
     const bool leftover = 8u * nraw < R;
-    if (total > a.packet_stride || (size_t)(R + 31u) / 32u > a.raw_words || (leftover && nbytes == 0)) {
-        if (tid == 0) { a.status[f] = leftover && nbytes == 0 ? -1 : -28; a.sizes[f] = 0; }
-        return;
-    }
-    // carry look-ahead over `top` bytes (daala_entropy.c:706-715): each thread resolves its chunk from
-    // the end for carry-in 0 and 1, thread 0 composes the 256 two-bit functions
+    // each thread resolves its chunk of the `top` bytes from the end for carry-in 0 and 1, thread 0
+    // composes the 256 two-bit functions
     const uint32_t per = (top + 255u) / 256u;
     const uint32_t i0 = (uint32_t)tid * per, i1 = i0 + per < top ? i0 + per : top;
     uint32_t k0 = 0, k1 = 1;
@@ -564,14 +589,9 @@ __global__ __launch_bounds__(256) void lc_finish_kernel(const FFV2LaneCoderArgs 
         if (i < nbytes) pkt[i] = (uint8_t)s;
         k = s >> 8;
     }
-    // raw bytes behind the range bytes in reverse write order (:676-721)
     for (uint32_t j = (uint32_t)tid; j < nraw; j += 256u) pkt[total - 1u - j] = (uint8_t)(raw[j >> 2] >> (8u * (j & 3u)));
     __syncthreads();
-    if (tid == 0) {
-        if (leftover) pkt[nbytes - 1u] |= (uint8_t)(raw[nraw >> 2] >> (8u * (nraw & 3u)));
-        a.status[f] = 0;
-        a.sizes[f] = total;
-    }
+    if (tid == 0 && leftover) pkt[nbytes - 1u] |= (uint8_t)(raw[nraw >> 2] >> (8u * (nraw & 3u)));
 }
 
 }  // namespace
@@ -592,6 +612,8 @@ hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStrea
 {
     hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, s, a);
     hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(128), 0, s, a, nframes);
-    hipLaunchKernelGGL(lc_finish_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lc_size_kernel, dim3((unsigned)nframes), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(lc_offsets_kernel, dim3(1), dim3(256), 0, s, a, nframes);
+    hipLaunchKernelGGL(lc_write_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);
     return hipGetLastError();
 }

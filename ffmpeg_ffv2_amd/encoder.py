@@ -39,6 +39,9 @@ class FFV2Encoder:
         if getattr(self, "_h", None):
             self._lib.ffv2amd_encoder_destroy(self._h)
             self._h = None
+            for ptr in getattr(self, "_lc_ptrs", []):        # lanecoder_finish's page-locked packet buffers
+                self._lib.ffv2amd_host_free(ptr)
+            self._lc_ptrs, self._lc_bufs = [], {}
 
     def __del__(self):
         try:
@@ -193,21 +196,17 @@ class FFV2Encoder:
 
     def lanecoder_encode(self, d_frames, qp, d_W=None, packet_stride=None, as_arrays=False):
         """Up to frames_in_flight frames in HBM -> packets, the range coder running one frame per lane.
-        as_arrays: return (packets[F, stride] uint8, sizes, status) without raising on a failed frame."""
-        F = d_frames.shape[0]
-        cap = int(packet_stride or self.info.packet_cap_qp)
-        key = (F, cap)
-        if getattr(self, "_lc_key", None) != key:
-            self._lc_out, self._lc_key = np.empty((F, cap), np.uint8), key
-        pk = self._lc_out
-        sizes = np.zeros(F, np.uint32)
-        status = np.zeros(F, np.int32)
-        _lib.check(self._lib.ffv2amd_lanecoder_encode(
-            self._h, F, d_frames.data_ptr(), qp, d_W.data_ptr() if d_W is not None else None,
-            pk.ctypes.data_as(C.c_void_p), cap, sizes.ctypes.data_as(C.c_void_p),
-            status.ctypes.data_as(C.c_void_p)), "ffv2amd_lanecoder_encode")
+        as_arrays: return (packets[F, stride] uint8, sizes, status) without raising on a failed frame
+        (the array is reused by the next call with the same shape)."""
+        if getattr(self, "_lc_pending", None):
+            raise _lib.FFV2Error(-22, "lanecoder_encode with submitted calls in flight")
+        _lib.check(self._lib.ffv2amd_lanecoder_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
+                                                      d_W.data_ptr() if d_W is not None else None), "ffv2amd_lanecoder_submit")
+        self._lc_pending = [(d_frames, d_W)]
+        pk, sizes, status = self.lanecoder_finish(packet_stride)
         if as_arrays:
             return pk, sizes, status
+        F = d_frames.shape[0]
         for f in range(F):
             if status[f] < 0:
                 raise _lib.FFV2Error(int(status[f]), "frame %d" % f)
@@ -231,7 +230,12 @@ class FFV2Encoder:
         cap = int(packet_stride or self.info.packet_cap_qp)
         bufs = getattr(self, "_lc_bufs", {})
         if (F, cap) not in bufs:
-            bufs[(F, cap)] = np.empty((F, cap), np.uint8)
+            # page-locked: the packets come back by DMA
+            ptr = self._lib.ffv2amd_host_alloc(F * cap)
+            if not ptr:
+                raise MemoryError("ffv2amd_host_alloc(%d)" % (F * cap))
+            self._lc_ptrs = getattr(self, "_lc_ptrs", []) + [ptr]
+            bufs[(F, cap)] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(F * cap,)).reshape(F, cap)
             self._lc_bufs = bufs
         pk = bufs[(F, cap)]
         sizes = np.zeros(F, np.uint32)
@@ -240,6 +244,30 @@ class FFV2Encoder:
                                                       sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)),
                    "ffv2amd_lanecoder_finish")
         return pk, sizes, status
+
+    def lanecoder_finish_packed(self):
+        """Packets of the oldest submitted call as they lie on the device, in one copy:
+        (buf uint8, offsets uint64, sizes, status); packet f = buf[offsets[f] : offsets[f] + sizes[f]].
+        buf is page-locked and reused by the next call with the same number of frames."""
+        d_frames, _ = self._lc_pending.pop(0)
+        F = d_frames.shape[0]
+        cap = F * ((getattr(self, "_lc_cap", 0) or self.info.packet_cap_qp) + 16)
+        bufs = getattr(self, "_lc_bufs", {})
+        if ("packed", cap) not in bufs:
+            ptr = self._lib.ffv2amd_host_alloc(cap)
+            if not ptr:
+                raise MemoryError("ffv2amd_host_alloc(%d)" % cap)
+            self._lc_ptrs = getattr(self, "_lc_ptrs", []) + [ptr]
+            bufs[("packed", cap)] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(cap,))
+            self._lc_bufs = bufs
+        buf = bufs[("packed", cap)]
+        offs = np.zeros(F, np.uint64)
+        sizes = np.zeros(F, np.uint32)
+        status = np.zeros(F, np.int32)
+        _lib.check(self._lib.ffv2amd_lanecoder_finish_packed(
+            self._h, buf.ctypes.data_as(C.c_void_p), cap, offs.ctypes.data_as(C.c_void_p),
+            sizes.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p)), "ffv2amd_lanecoder_finish_packed")
+        return buf, offs, sizes, status
 
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""

@@ -176,8 +176,14 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  *                      Two calls may be in flight (FFV2AMD_ERR_AGAIN for a third): the transform,
  *                      PVQ search and symbol bookkeeping of call n+1 then run beside the range
  *                      chain of call n, which occupies a small part of the chip.
- *   lanecoder_finish : the oldest submitted call -> packets in host memory, byte-identical to
- *                      ffv2amd_encode_batch_to_host at the same qp.  Per-frame status as there
+ *   lanecoder_finish : the oldest submitted call -> packets in host memory (packet f at h_packets +
+ *                      f * packet_stride), byte-identical to ffv2amd_encode_batch_to_host at the
+ *                      same qp; one device-to-host copy per packet.
+ *   lanecoder_finish_packed : the same packets as they lie on the device: back to back (each
+ *                      at a 16-byte aligned h_offsets[f]) in ONE copy of h_offsets-total bytes --
+ *                      the fast way out for thousands of packets; page-locked h_buf
+ *                      (ffv2amd_host_alloc) for full PCIe rate.  FFV2AMD_ERR_NOSPACE (call stays
+ *                      queued) when h_cap is too small: frames * packet_cap always suffices.  Per-frame status as there
  *                      (FFV2AMD_ERR_ABORT where the reference would av_assert0).
  *   lanecoder_encode : submit + finish.
  * One thread drives a coder.  PARITY UNPINNED like all of qp > 0. */
@@ -187,6 +193,8 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc, size_t pack
 int    ffv2amd_lanecoder_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int    ffv2amd_lanecoder_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);
+int    ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *enc, uint8_t *h_buf, size_t h_cap, uint64_t *h_offsets,
+                                       uint32_t *h_sizes, int32_t *h_status);
 int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp,
                                 const int32_t *d_W, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

@@ -163,6 +163,11 @@ def test_lanecoder_two_calls_in_flight(oracle):
         assert not status.any()
         got.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))])
     assert got == want
+    # the same packets as they lie on the device, in one copy
+    assert enc.lanecoder_submit(dev[0], qp)
+    buf, offs, sizes, status = enc.lanecoder_finish_packed()
+    assert not status.any() and all(int(o) % 16 == 0 for o in offs)
+    assert [buf[int(o): int(o) + int(n)].tobytes() for o, n in zip(offs, sizes)] == want[0]
     enc.close()
 
 

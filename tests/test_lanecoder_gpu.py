@@ -191,3 +191,18 @@ def test_lanecoder_small_packet_cap_reports_nospace(oracle):
     pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
     assert [pk[i, : sizes[i]].tobytes() for i in range(2)] == want
     enc.close()
+
+
+def test_lanecoder_phantom_coefficient_w(oracle):
+    """the phantom 2049th coefficient of band 12 (W, per block-plane) takes part in the gain
+    and the PVQ search; frames of a call beyond the first T-stage batch must pick up their own W."""
+    import torch
+    W, H, fmt, P, depth, qp, n = 130, 70, "yuv444p", 3, 8, 16, 5
+    enc = _enc(W, H, fmt, 2)
+    frames = np.stack([synth.noise(50 + i, P, H, W, depth) for i in range(n)])
+    Wv = np.random.default_rng(9).integers(-3000, 3000, (n, enc.info.block_planes)).astype(np.int32)
+    enc.lanecoder_open(n)
+    pk, sizes, status = enc.lanecoder_encode(enc.upload(frames), qp, d_W=torch.from_numpy(Wv).cuda(), as_arrays=True)
+    for i in range(n):
+        assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == oracle.encode(frames[i], fmt, qp=qp, W=Wv[i]), i
+    enc.close()

@@ -174,8 +174,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None, help="default 200 (qp 0), 6 with --qp on the device coder")
+    ap.add_argument("--warmup", type=int, default=None, help="default 50 (qp 0), 1 with --qp on the device coder")
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--frames-per-step", type=int, default=8)
     ap.add_argument("--no-coef", action="store_true", help="do not materialise coefficients (fused qp=0 path)")
@@ -192,7 +192,10 @@ def main():
     ap.add_argument("--ring-depth", type=int, default=4)
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="with --qp: the many-frames-in-flight device coder (ffv2_lanecoder.hip, one frame per lane of the "
-                         "range chain); a step is one call over this many device-resident frames")
+                         "range chain); a step is one call over this many device-resident frames.  Default: what "
+                         "160 GB of coder scratch hold at 700 B per block-plane and packet, at most 2048")
+    ap.add_argument("--host-coder", action="store_true",
+                    help="with --qp: the GPU + host-threads pipeline (ffv2amd_qp_submit/_finish) instead of the device coder")
     ap.add_argument("--strided-packets", action="store_true",
                     help="with --frames-in-flight: packets come back one copy each into a [frames][stride] array "
                          "(ffv2amd_lanecoder_finish) instead of packed in one copy (ffv2amd_lanecoder_finish_packed)")
@@ -201,6 +204,11 @@ def main():
     ap.add_argument("--qp", type=int, default=0,
                     help="informational: qp > 0 times ffv2amd_encode_batch_to_host (GPU transform + PVQ, host range coder)")
     args = ap.parse_args()
+    lane_mode = args.qp > 0 and not args.host_coder and not args.device_coder
+    if args.steps is None:
+        args.steps = 6 if lane_mode else 200
+    if args.warmup is None:
+        args.warmup = 1 if lane_mode else 50
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -246,7 +254,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.qp > 0 and args.frames_in_flight > 0:
+    if lane_mode:
+        if args.frames_in_flight <= 0:
+            if not args.packet_cap:
+                args.packet_cap = 4096 + 700 * enc.info.block_planes      # noise at qp 16 / 64 codes to 160 / 370 B per block-plane
+            per = enc.lanecoder_bytes_per_frame(args.packet_cap)
+            args.frames_in_flight = max(64, min(2048, int(160e9 // per) // 64 * 64))
         lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
         return
     if args.qp > 0:

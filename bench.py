@@ -145,6 +145,11 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                           "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap) / 1e9, 1),
                           "packet_cap": args.packet_cap or enc.info.packet_cap_qp,
                           "packets_out": "one copy per packet" if args.strided_packets else "packed, one copy"},
+               "chain": dict(zip(("kernel", "ms", "back_ms", "symbols_frame0", "ns_per_symbol", "what"),
+                                 ("lc_chain_kernel",) + (lambda c, b, n: (round(c, 2), round(b, 2), n, round(c * 1e6 / max(n, 1), 1)))(
+                                     *enc.lanecoder_stats()) +
+                                 ("the range recurrence, one frame per lane: its time does not depend on the frames in flight; "
+                                  "bound by the issue rate of a lone wavefront, not by HBM or MFMA (last step's values)",))),
                "roofline": None}
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib

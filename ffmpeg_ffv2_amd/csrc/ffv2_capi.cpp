@@ -576,11 +576,14 @@ struct ffv2amd_encoder {
             uint32_t *h_sizes = nullptr;
             int32_t *h_status = nullptr;
             hipEvent_t ev_front = nullptr, ev_done = nullptr;
+            hipEvent_t ev_back0 = nullptr, ev_chain0 = nullptr, ev_chain1 = nullptr;   // timing: back begins, chain begins / ends
             int nframes = 0;
             bool busy = false;
         } set[2];
         hipStream_t back = nullptr, copy = nullptr;
         unsigned sub = 0, fin = 0;
+        float last_chain_ms = 0, last_back_ms = 0;   // of the call finished last (ffv2amd_lanecoder_stats)
+        uint32_t last_symbols0 = 0;
         std::vector<void *> allocs;      // every device buffer above, for close
     } lc;
 };
@@ -1176,9 +1179,12 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
     for (auto &q : lc.set) {
         HIPCHK(hipHostMalloc(&q.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&q.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc(&q.h_offs, sizeof(unsigned long long) * (F + 1), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&q.h_offs, sizeof(unsigned long long) * (F + 2), hipHostMallocDefault));   // [F + 1]: symbols of frame 0
         HIPCHK(hipEventCreateWithFlags(&q.ev_front, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&q.ev_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&q.ev_done));
+        HIPCHK(hipEventCreate(&q.ev_back0));
+        HIPCHK(hipEventCreate(&q.ev_chain0));
+        HIPCHK(hipEventCreate(&q.ev_chain1));
     }
     HIPCHK(hipStreamCreateWithFlags(&lc.back, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&lc.copy, hipStreamNonBlocking));
@@ -1216,6 +1222,9 @@ static void lanecoder_free(ffv2amd_encoder *e)
         if (q.h_offs) (void)hipHostFree(q.h_offs);
         if (q.ev_front) (void)hipEventDestroy(q.ev_front);
         if (q.ev_done) (void)hipEventDestroy(q.ev_done);
+        if (q.ev_back0) (void)hipEventDestroy(q.ev_back0);
+        if (q.ev_chain0) (void)hipEventDestroy(q.ev_chain0);
+        if (q.ev_chain1) (void)hipEventDestroy(q.ev_chain1);
     }
     lc = ffv2amd_encoder::LaneCoder{};
 }
@@ -1257,6 +1266,25 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet
     const size_t per_set = (nb * 4097 + 255) / 256 * 256 + packet_cap * 2
                          + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
     return shared + 2 * per_set;
+}
+
+// timing of the call that has just completed (events recorded on the back stream)
+static void lanecoder_note_times(ffv2amd_encoder::LaneCoder &lc, ffv2amd_encoder::LaneCoder::Set &q)
+{
+    float c = 0, b = 0;
+    if (hipEventElapsedTime(&c, q.ev_chain0, q.ev_chain1) != hipSuccess) c = 0;
+    if (hipEventElapsedTime(&b, q.ev_back0, q.ev_done) != hipSuccess) b = 0;
+    lc.last_chain_ms = c; lc.last_back_ms = b;
+    lc.last_symbols0 = *reinterpret_cast<const uint32_t *>(q.h_offs + (size_t)lc.cap + 1);
+}
+
+int ffv2amd_lanecoder_stats(const ffv2amd_encoder *e, float *chain_ms, float *back_ms, uint32_t *symbols_frame0)
+{
+    if (!e || !e->lc.cap) return FFV2AMD_ERR_INVAL;
+    if (chain_ms) *chain_ms = e->lc.last_chain_ms;
+    if (back_ms) *back_ms = e->lc.last_back_ms;
+    if (symbols_frame0) *symbols_frame0 = e->lc.last_symbols0;
+    return FFV2AMD_OK;
 }
 
 int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, const int32_t *d_W)
@@ -1308,10 +1336,12 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     HIPCHK(hipEventRecord(q.ev_front, s));
     // back: cdf, chain, packets.  One call's back runs at a time (its scratch exists once).
     HIPCHK(hipStreamWaitEvent(lc.back, q.ev_front, 0));
-    HIPCHK(ffv2_launch_lc_back(a, nframes, lc.back));
+    HIPCHK(hipEventRecord(q.ev_back0, lc.back));
+    HIPCHK(ffv2_launch_lc_back(a, nframes, lc.back, q.ev_chain0, q.ev_chain1));
     HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_offs, q.offs, sizeof(unsigned long long) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, lc.back));
+    HIPCHK(hipMemcpyAsync(q.h_offs + (size_t)lc.cap + 1, q.gbase + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipEventRecord(q.ev_done, lc.back));
     q.nframes = nframes; q.busy = true;
     lc.sub++;
@@ -1327,6 +1357,7 @@ int ffv2amd_lanecoder_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t pack
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     auto &q = lc.set[lc.fin & 1u];
     HIPCHK(hipEventSynchronize(q.ev_done));
+    lanecoder_note_times(lc, q);
     // packets on the copy stream (the back stream may already hold the next call): they lie packed
     // on the device, each goes to its own row of the caller's array
     for (int f = 0; f < q.nframes; f++) {
@@ -1354,6 +1385,7 @@ int ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *e, uint8_t *h_buf, size_t h
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     auto &q = lc.set[lc.fin & 1u];
     HIPCHK(hipEventSynchronize(q.ev_done));
+    lanecoder_note_times(lc, q);
     const size_t total = (size_t)q.h_offs[q.nframes];
     if (total > h_cap) return FFV2AMD_ERR_NOSPACE;               // the call stays queued: finish it with a larger buffer
     // the packets lie packed on the device: one copy

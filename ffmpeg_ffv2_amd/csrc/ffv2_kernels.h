@@ -132,4 +132,5 @@ struct FFV2LaneCoderArgs {
     uint4 *fin;                       // [F] range bytes, slack bits, bytes the carry chain covers
 };
 hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
-hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s);                      // cdf, chain, finish of frames 0..nframes-1
+hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s,                      // cdf, chain, finish of frames 0..nframes-1;
+                               hipEvent_t chain_begin, hipEvent_t chain_end);                             // optional timing events around the chain kernel

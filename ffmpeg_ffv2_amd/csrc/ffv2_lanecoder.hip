@@ -608,10 +608,12 @@ hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, in
     return hipGetLastError();
 }
 
-hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s)
+hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s, hipEvent_t chain_begin, hipEvent_t chain_end)
 {
     hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, s, a);
+    if (chain_begin) (void)hipEventRecord(chain_begin, s);
     hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(128), 0, s, a, nframes);
+    if (chain_end) (void)hipEventRecord(chain_end, s);
     hipLaunchKernelGGL(lc_size_kernel, dim3((unsigned)nframes), dim3(64), 0, s, a);
     hipLaunchKernelGGL(lc_offsets_kernel, dim3(1), dim3(256), 0, s, a, nframes);
     hipLaunchKernelGGL(lc_write_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);

@@ -245,6 +245,12 @@ class FFV2Encoder:
                    "ffv2amd_lanecoder_finish")
         return pk, sizes, status
 
+    def lanecoder_stats(self):
+        """(chain kernel ms, whole back ms, symbols of frame 0) of the call finished last."""
+        c, b, n = C.c_float(0), C.c_float(0), C.c_uint32(0)
+        _lib.check(self._lib.ffv2amd_lanecoder_stats(self._h, C.byref(c), C.byref(b), C.byref(n)), "ffv2amd_lanecoder_stats")
+        return c.value, b.value, n.value
+
     def lanecoder_finish_packed(self):
         """Packets of the oldest submitted call as they lie on the device, in one copy:
         (buf uint8, offsets uint64, sizes, status); packet f = buf[offsets[f] : offsets[f] + sizes[f]].

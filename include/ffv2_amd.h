@@ -195,6 +195,9 @@ int    ffv2amd_lanecoder_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t
                                 uint32_t *h_sizes, int32_t *h_status);
 int    ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *enc, uint8_t *h_buf, size_t h_cap, uint64_t *h_offsets,
                                        uint32_t *h_sizes, int32_t *h_status);
+/* Timing of the call finished last: its range-chain kernel and its whole back (cdf, chain, packets), in ms on
+ * the device clock, and the symbols the coder read for the call's first frame.  For benchmarks. */
+int    ffv2amd_lanecoder_stats(const ffv2amd_encoder *enc, float *chain_ms, float *back_ms, uint32_t *symbols_frame0);
 int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp,
                                 const int32_t *d_W, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

@@ -346,8 +346,8 @@ typedef unsigned short lc_us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t lc_recur(uint32_t &rng, uint32_t lo, uint32_t ft)
 {
-    // daala_entropy.c:362-378 with as few instructions as I could find (a lone wavefront pays ~6.5
-    // cycles for each, dependent or not).  The reference scales fl, fh, ft by two when
+    // daala_entropy.c:362-378 in as few instructions as possible (a lone wavefront pays ~6.5 cycles
+    // for each, dependent or not).  The reference scales fl, fh, ft by two when
     // rng - ft >= ft; with t = rng - ft and x = t - ft that is x >= 0 and then d = rng - 2 ft = x,
     // else d = t: d = min(t, x) as unsigned numbers.  g = sat(2 d - ft') with ft' = rng - d is
     // sat(3 d - rng).  Scaling needs ft < 32768, so fh << 1 < 65536 and both halves of `lo` shift in

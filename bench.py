@@ -104,7 +104,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     d = enc.upload(host_frames)
     d_frames = d.repeat((F + distinct - 1) // distinct, *([1] * (d.dim() - 1)))[:F].contiguous()
     del d
-    enc.lanecoder_open(F, args.packet_cap)
+    enc.lanecoder_open(F, args.packet_cap, args.calls_in_flight)
     def finish():
         if not args.strided_packets:
             return enc.lanecoder_finish_packed()
@@ -120,9 +120,11 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     # two calls in flight: the front of step i+1 (T-stage, PVQ, bookkeeping) runs beside the chain of
     # step i; the packets of a step come back packed, in one copy
     t0 = time.perf_counter()
-    enc.lanecoder_submit(d_frames, args.qp)
+    ahead = args.calls_in_flight - 1
+    for i in range(min(ahead, args.steps)):
+        enc.lanecoder_submit(d_frames, args.qp)
     for i in range(args.steps):
-        if i + 1 < args.steps:
+        if i + ahead < args.steps:
             enc.lanecoder_submit(d_frames, args.qp)
         buf, offs, sizes, status = finish()
     barrier()
@@ -142,7 +144,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                                       "frames resident in HBM, packets to host memory" % (W, H, fmt, args.qp, F, distinct),
                           "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
                           "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
-                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap) / 1e9, 1),
+                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight) / 1e9, 1),
+                          "calls_in_flight": args.calls_in_flight,
                           "packet_cap": args.packet_cap or enc.info.packet_cap_qp,
                           "packets_out": "one copy per packet" if args.strided_packets else "packed, one copy"},
                "chain": dict(zip(("kernel", "ms", "back_ms", "symbols_frame0", "ns_per_symbol", "what"),
@@ -204,6 +207,9 @@ def main():
     ap.add_argument("--strided-packets", action="store_true",
                     help="with --frames-in-flight: packets come back one copy each into a [frames][stride] array "
                          "(ffv2amd_lanecoder_finish) instead of packed in one copy (ffv2amd_lanecoder_finish_packed)")
+    ap.add_argument("--calls-in-flight", type=int, default=2, choices=(2, 3),
+                    help="with --qp on the device coder: submitted calls before a finish is due (each holds its own copy of "
+                         "the front's buffers)")
     ap.add_argument("--packet-cap", type=int, default=0,
                     help="with --frames-in-flight: bytes of HBM reserved per packet (0 = the encoder's bound for any qp)")
     ap.add_argument("--qp", type=int, default=0,
@@ -263,7 +269,7 @@ def main():
         if args.frames_in_flight <= 0:
             if not args.packet_cap:
                 args.packet_cap = 4096 + 700 * enc.info.block_planes      # noise at qp 16 / 64 codes to 160 / 370 B per block-plane
-            per = enc.lanecoder_bytes_per_frame(args.packet_cap)
+            per = enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight)
             args.frames_in_flight = max(64, min(2048, int(160e9 // per) // 64 * 64))
         lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
         return

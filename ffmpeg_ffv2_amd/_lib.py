@@ -102,9 +102,9 @@ def load():
     lib.ffv2amd_encoder_set_device_coder.argtypes = [C.c_void_p, C.c_int]
     lib.ffv2amd_qp_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ffv2amd_qp_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    lib.ffv2amd_lanecoder_open.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    lib.ffv2amd_lanecoder_open.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int]
     lib.ffv2amd_lanecoder_close.argtypes = [C.c_void_p]
-    lib.ffv2amd_lanecoder_bytes_per_frame.argtypes = [C.c_void_p, C.c_size_t]
+    lib.ffv2amd_lanecoder_bytes_per_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     lib.ffv2amd_lanecoder_bytes_per_frame.restype = C.c_size_t
     lib.ffv2amd_lanecoder_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ffv2amd_lanecoder_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -579,7 +579,8 @@ struct ffv2amd_encoder {
             hipEvent_t ev_back0 = nullptr, ev_chain0 = nullptr, ev_chain1 = nullptr;   // timing: back begins, chain begins / ends
             int nframes = 0;
             bool busy = false;
-        } set[2];
+        } set[3];
+        int nsets = 2;                   // calls in flight (2 or 3): how many of the sets are in use
         hipStream_t back = nullptr, copy = nullptr;
         unsigned sub = 0, fin = 0;
         float last_chain_ms = 0, last_back_ms = 0;   // of the call finished last (ffv2amd_lanecoder_stats)
@@ -1138,9 +1139,11 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
 // stream (the "front"), then queues the CDF, chain and packet kernels over all of them on a second
 // stream (the "back").  The back's scratch (records, code words) exists once, the front's twice:
 // submit(n+1) before finish(n) runs the front of call n+1 beside the chain of call n, which keeps
-// only 1/16 of the chip's SIMDs busy.
+// only 1/16 of the chip's SIMDs busy.  With a third set (calls_in_flight = 3) the fronts follow each other
+// without waiting for a finish: the period of back-to-back calls falls from (back + front + copy) / 2 to
+// max(back, front).
 // ------------------------------------------------------------------
-static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
+static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nsets)
 {
     auto &lc = e->lc;
     const ffv2amd_info &in = e->info;
@@ -1151,6 +1154,7 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
         return true;
     };
     FFV2LaneCoderArgs &a = lc.a;
+    lc.nsets = nsets;
     a.nblk = (int)nb; a.planes = in.planes;
     int width = 1;
     while (width < frames && width < 64) width <<= 1;
@@ -1164,7 +1168,8 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
     a.packet_stride = pcap;
     bool ok = dev(&a.recs, sizeof(uint2) * a.group_stride * groups) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
            && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.fin, sizeof(uint4) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
-    for (auto &q : lc.set) {
+    for (int k = 0; k < nsets; k++) {
+        auto &q = lc.set[k];
         ok = ok && dev(&q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
            && dev(&q.d_status_in, sizeof(int32_t) * F) && dev(&q.abort_, sizeof(int32_t) * F)
            && dev(&q.cnt, sizeof(FFV2SymRec) * nb * F) && dev(&q.bits, sizeof(uint32_t) * nb * F)
@@ -1176,7 +1181,8 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap)
     }
     if (!ok) return FFV2AMD_ERR_NOMEM;
     a.split = lc.d_split;
-    for (auto &q : lc.set) {
+    for (int k = 0; k < nsets; k++) {
+        auto &q = lc.set[k];
         HIPCHK(hipHostMalloc(&q.h_sizes, sizeof(uint32_t) * F, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&q.h_status, sizeof(int32_t) * F, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&q.h_offs, sizeof(unsigned long long) * (F + 2), hipHostMallocDefault));   // [F + 1]: symbols of frame 0
@@ -1229,9 +1235,11 @@ static void lanecoder_free(ffv2amd_encoder *e)
     lc = ffv2amd_encoder::LaneCoder{};
 }
 
-int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t packet_cap)
+int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t packet_cap, int calls_in_flight)
 {
     if (!e || frames_in_flight < 1 || frames_in_flight > (1 << 20)) return FFV2AMD_ERR_INVAL;
+    if (calls_in_flight == 0) calls_in_flight = 2;
+    if (calls_in_flight < 2 || calls_in_flight > 3) return FFV2AMD_ERR_INVAL;
     if (packet_cap == 0 || packet_cap > e->info.packet_cap_qp) packet_cap = e->info.packet_cap_qp;
     if (packet_cap < 64) return FFV2AMD_ERR_INVAL;
     packet_cap = (packet_cap + 15) / 16 * 16;
@@ -1241,7 +1249,7 @@ int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t pack
         HIPCHK(hipStreamSynchronize(e->stream));
         lanecoder_free(e);
     }
-    const int r = lanecoder_alloc(e, frames_in_flight, packet_cap);
+    const int r = lanecoder_alloc(e, frames_in_flight, packet_cap, calls_in_flight);
     if (r < 0) lanecoder_free(e);
     return r;
 }
@@ -1256,7 +1264,7 @@ int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
     return FFV2AMD_OK;
 }
 
-size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet_cap)
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet_cap, int calls_in_flight)
 {
     if (!e) return 0;
     const ffv2amd_info &in = e->info;
@@ -1265,7 +1273,7 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet
     const size_t shared = ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + packet_cap * 2 + 256;
     const size_t per_set = (nb * 4097 + 255) / 256 * 256 + packet_cap * 2
                          + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
-    return shared + 2 * per_set;
+    return shared + (size_t)(calls_in_flight == 3 ? 3 : 2) * per_set;
 }
 
 // timing of the call that has just completed (events recorded on the back stream)
@@ -1293,8 +1301,8 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
     auto &lc = e->lc;
     if (nframes > lc.cap) return FFV2AMD_ERR_INVAL;
-    auto &q = lc.set[lc.sub & 1u];
-    if (q.busy) return FFV2AMD_ERR_AGAIN;                        // two calls already in flight
+    auto &q = lc.set[lc.sub % (unsigned)lc.nsets];
+    if (q.busy) return FFV2AMD_ERR_AGAIN;                        // every set is in flight
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const ffv2amd_info &in = e->info;
@@ -1355,7 +1363,7 @@ int ffv2amd_lanecoder_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t pack
     if (lc.fin == lc.sub) return FFV2AMD_ERR_AGAIN;              // nothing submitted
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
-    auto &q = lc.set[lc.fin & 1u];
+    auto &q = lc.set[lc.fin % (unsigned)lc.nsets];
     HIPCHK(hipEventSynchronize(q.ev_done));
     lanecoder_note_times(lc, q);
     // packets on the copy stream (the back stream may already hold the next call): they lie packed
@@ -1383,7 +1391,7 @@ int ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *e, uint8_t *h_buf, size_t h
     if (lc.fin == lc.sub) return FFV2AMD_ERR_AGAIN;              // nothing submitted
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
-    auto &q = lc.set[lc.fin & 1u];
+    auto &q = lc.set[lc.fin % (unsigned)lc.nsets];
     HIPCHK(hipEventSynchronize(q.ev_done));
     lanecoder_note_times(lc, q);
     const size_t total = (size_t)q.h_offs[q.nframes];

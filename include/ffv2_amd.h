@@ -173,7 +173,8 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  *                      qp 16 / 64 codes to 160 / 370 bytes per block-plane).
  *   lanecoder_submit : up to that many device-resident frames (layout of ffv2amd_info), qp 1..64.
  *                      Asynchronous; the frames (and W) stay untouched until the call's finish.
- *                      Two calls may be in flight (FFV2AMD_ERR_AGAIN for a third): the transform,
+ *                      calls_in_flight (2, or 3; 0 = 2) calls may be in flight (FFV2AMD_ERR_AGAIN
+ *                      for one more; each holds its own copy of the smaller buffers): the transform,
  *                      PVQ search and symbol bookkeeping of call n+1 then run beside the range
  *                      chain of call n, which occupies a small part of the chip.
  *   lanecoder_finish : the oldest submitted call -> packets in host memory (packet f at h_packets +
@@ -187,9 +188,9 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  *                      (FFV2AMD_ERR_ABORT where the reference would av_assert0).
  *   lanecoder_encode : submit + finish.
  * One thread drives a coder.  PARITY UNPINNED like all of qp > 0. */
-int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap);
+int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap, int calls_in_flight);
 int    ffv2amd_lanecoder_close(ffv2amd_encoder *enc);
-size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc, size_t packet_cap);
+size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc, size_t packet_cap, int calls_in_flight);
 int    ffv2amd_lanecoder_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int    ffv2amd_lanecoder_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

@@ -163,6 +163,12 @@ def test_lanecoder_two_calls_in_flight(oracle):
         assert not status.any()
         got.append([pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))])
     assert got == want
+    # three calls in flight: no finish is due between the submits
+    enc.lanecoder_open(5, calls_in_flight=3)
+    assert all(enc.lanecoder_submit(dev[c], qp) for c in range(3)) and not enc.lanecoder_submit(dev[0], qp)
+    for c in range(3):
+        pk, sizes, status = enc.lanecoder_finish()
+        assert not status.any() and [pk[i, : sizes[i]].tobytes() for i in range(len(calls[c]))] == want[c], c
     # the same packets as they lie on the device, in one copy
     assert enc.lanecoder_submit(dev[0], qp)
     buf, offs, sizes, status = enc.lanecoder_finish_packed()

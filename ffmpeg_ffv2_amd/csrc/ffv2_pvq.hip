@@ -68,27 +68,37 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
     }
     const float b = __fdiv_rn((float)K, Sx);
     int sy = 0;
+    bool anyy = false;
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        const int i = lane + 64 * m;
         const int yt = __float2int_rn(__fmul_rn(b, ax[m]));   // cvtps2dq: round to nearest even
         fy[m] = (float)yt;
         sy += yt;
-        if (i < N4) L.s[i] = __fmul_rn(ax[m], fy[m]);
+        anyy = anyy || yt != 0;
     }
-    __syncthreads();
-    c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
-    float Sxy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
-    __syncthreads();
+    float Sxy = 0.0f, Syy = 0.0f;
+    // Sxy and Syy are sums in the asm's order; when the projection leaves every y at zero (flat
+    // spectra: K pulses spread over N >> K coefficients) every term is +0 and so are the sums
+    if (__ballot(anyy)) {
 #pragma unroll
-    for (int m = 0; m < M; m++) {
-        const int i = lane + 64 * m;
-        if (i < N4) L.s[i] = __fmul_rn(fy[m], fy[m]);
+        for (int m = 0; m < M; m++) {
+            const int i = lane + 64 * m;
+            if (i < N4) L.s[i] = __fmul_rn(ax[m], fy[m]);
+        }
+        __syncthreads();
+        c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
+        Sxy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int i = lane + 64 * m;
+            if (i < N4) L.s[i] = __fmul_rn(fy[m], fy[m]);
+        }
+        __syncthreads();
+        c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
+        Syy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
+        __syncthreads();
     }
-    __syncthreads();
-    c = lane < 4 ? chain_desc(L.s, nv, lane) : 0.0f;
-    float Syy = hsum4(__shfl(c, 0, 64), __shfl(c, 1, 64), __shfl(c, 2, 64), __shfl(c, 3, 64));
-    __syncthreads();
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sy += __shfl_xor(sy, o, 64);   // integer: any order
     int Kr = K - sy;

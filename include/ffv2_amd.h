@@ -165,7 +165,8 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  * carry propagation) data-parallel.  Throughput grows with the frames in flight until the other
  * kernels bound it; a call takes at least one frame's chain (about 75 ns per symbol).
  *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call
- *                      (ffv2amd_lanecoder_bytes_per_frame() each: 84 MB per 1080p frame);
+ *                      (ffv2amd_lanecoder_bytes_per_frame() each: 84 MB per 1080p frame with the
+ *                      default packet_cap and two calls in flight);
  *                      FFV2AMD_ERR_NOMEM if the device cannot hold it.  packet_cap = 0 reserves
  *                      ffv2amd_info.packet_cap_qp bytes per packet (2 100 per block-plane, six
  *                      buffers of that size per frame); a smaller packet_cap saves HBM, and a frame
@@ -179,13 +180,13 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  *                      chain of call n, which occupies a small part of the chip.
  *   lanecoder_finish : the oldest submitted call -> packets in host memory (packet f at h_packets +
  *                      f * packet_stride), byte-identical to ffv2amd_encode_batch_to_host at the
- *                      same qp; one device-to-host copy per packet.
- *   lanecoder_finish_packed : the same packets as they lie on the device: back to back (each
- *                      at a 16-byte aligned h_offsets[f]) in ONE copy of h_offsets-total bytes --
- *                      the fast way out for thousands of packets; page-locked h_buf
- *                      (ffv2amd_host_alloc) for full PCIe rate.  FFV2AMD_ERR_NOSPACE (call stays
- *                      queued) when h_cap is too small: frames * packet_cap always suffices.  Per-frame status as there
+ *                      same qp; one device-to-host copy per packet.  Per-frame status as there
  *                      (FFV2AMD_ERR_ABORT where the reference would av_assert0).
+ *   lanecoder_finish_packed : the same packets as they lie on the device: back to back, packet f
+ *                      at h_buf + h_offsets[f] (16-byte aligned), brought over in a few large
+ *                      copies -- the fast way out for thousands of packets; page-locked h_buf
+ *                      (ffv2amd_host_alloc) for full PCIe rate.  FFV2AMD_ERR_NOSPACE (the call stays
+ *                      queued) when h_cap is too small: frames * (packet_cap + 16) always suffices.
  *   lanecoder_encode : submit + finish.
  * One thread drives a coder.  PARITY UNPINNED like all of qp > 0. */
 int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap, int calls_in_flight);

@@ -212,3 +212,18 @@ def test_lanecoder_phantom_coefficient_w(oracle):
     for i in range(n):
         assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == oracle.encode(frames[i], fmt, qp=qp, W=Wv[i]), i
     enc.close()
+
+
+def test_lanecoder_frame_with_out_of_depth_samples_fails_alone(oracle):
+    """A frame the T-stage refuses (sample above the declared depth -> ERANGE, include/ffv2_amd.h) comes back
+    with that status; its neighbours in the same group of lanes are coded as usual."""
+    W, H, fmt, P, depth, qp = 96, 80, "yuv444p10le", 3, 10, 16
+    enc = _enc(W, H, fmt, 2)
+    frames = np.stack([synth.noise(70 + i, P, H, W, depth) for i in range(4)])
+    frames[2, 1, 40, 50] = 1500                      # 11-bit value in a 10-bit format
+    enc.lanecoder_open(4)
+    pk, sizes, status = enc.lanecoder_encode(enc.upload(frames), qp, as_arrays=True)
+    assert list(status) == [0, 0, -34, 0]
+    for i in (0, 1, 3):
+        assert pk[i, : sizes[i]].tobytes() == oracle.encode(frames[i], fmt, qp=qp), i
+    enc.close()

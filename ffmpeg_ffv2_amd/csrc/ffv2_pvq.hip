@@ -104,6 +104,12 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
     int Kr = K - sy;
     if (Kr != 0) {
         const bool add = Kr > 0;
+        // every non-zero |x| within [2^-40, 2^40] (normalised coefficients are: 1 / (45 * 2^22) <= |x| <= 1):
+        // the shared-denominator division below then never meets a scaled or special operand
+        bool wild = false;
+#pragma unroll
+        for (int m = 0; m < M; m++) wild = wild || (ax[m] != 0.0f && !(ax[m] >= 0x1p-40f && ax[m] <= 0x1p40f));
+        const bool tame = __ballot(wild) == 0 && K <= 4096;
         Syy = __fmul_rn(Syy, 0.5f);
         for (int it = add ? Kr : -Kr; it > 0; it--) {
             Syy = __fadd_rn(Syy, 0.5f);
@@ -111,19 +117,46 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
             // better the class winner is its lowest index (the asm's initial max_idx)
             float bp = lane < N4 ? 0.0f : -1.0f;
             int bi = lane < N4 ? lane : 0x7fffffff;
+            if (add && tame) {
+                // Elements without a pulse share the denominator 0 + Syy = Syy.  The IEEE division is
+                // the sequence rcp, two FMAs refining it, q0 = n r, and three FMA corrections of q;
+                // v_div_scale / v_div_fmas / v_div_fixup only act on operands near the ends of the
+                // exponent range, which `tame` excludes (0.5 <= Syy <= 2 K^2; the numerator
+                // (|x| + Sxy)^2 is 0 or within [2^-80, 2^90]).  The first three steps depend on the
+                // denominator alone and are done once per pulse; a slot (64 elements) in which some
+                // lane's element carries a pulse takes the full division.
+                const float r0 = __builtin_amdgcn_rcpf(Syy);
+                const float r1 = __fmaf_rn(__fmaf_rn(-Syy, r0, 1.0f), r0, r0);
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const int i = lane + 64 * m;
-                float num, den;
-                if (add) {
-                    den = __fadd_rn(fy[m], Syy);
-                    num = __fadd_rn(ax[m], Sxy);
-                } else {
-                    den = __fsub_rn(Syy, fy[m]);
-                    num = (0.0f < fy[m]) ? __fsub_rn(Sxy, ax[m]) : 0.0f;
+                for (int m = 0; m < M; m++) {
+                    const int i = lane + 64 * m;
+                    const float num = __fadd_rn(ax[m], Sxy);
+                    const float n2 = __fmul_rn(num, num);
+                    float pp;
+                    if (__ballot(fy[m] != 0.0f) == 0) {
+                        const float q0 = __fmul_rn(n2, r1);
+                        const float q1 = __fmaf_rn(__fmaf_rn(-Syy, q0, n2), r1, q0);
+                        pp = __fmaf_rn(__fmaf_rn(-Syy, q1, n2), r1, q1);
+                    } else {
+                        pp = __fdiv_rn(n2, __fadd_rn(fy[m], Syy));
+                    }
+                    if (i < N4 && bp < pp) { bp = pp; bi = i; }
                 }
-                const float pp = __fdiv_rn(__fmul_rn(num, num), den);
-                if (i < N4 && bp < pp) { bp = pp; bi = i; }
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int i = lane + 64 * m;
+                    float num, den;
+                    if (add) {
+                        den = __fadd_rn(fy[m], Syy);
+                        num = __fadd_rn(ax[m], Sxy);
+                    } else {
+                        den = __fsub_rn(Syy, fy[m]);
+                        num = (0.0f < fy[m]) ? __fsub_rn(Sxy, ax[m]) : 0.0f;
+                    }
+                    const float pp = __fdiv_rn(__fmul_rn(num, num), den);
+                    if (i < N4 && bp < pp) { bp = pp; bi = i; }
+                }
             }
             // same class across lanes (lane ^ 4, 8, 16, 32): larger p, then lower index
 #pragma unroll

@@ -13,6 +13,12 @@ step    : one ffv2amd_encode_batch_device call = T-stage kernel + E-stage kernel
 N > 1   : frames are independent (no inter-frame state, ffv2enc.c:461-469), so
           each rank encodes its own frames: weak scaling, no data-path collective;
           RCCL is used only for the barrier and the max-over-ranks time.
+--qp N  : (not the BASELINE metric) the qp > 0 path with the whole entropy coder on the
+          device, the range coder's serial chain running one frame per lane over many
+          frames in flight (ffv2_lanecoder.hip): a step is one call over --frames-in-flight
+          device-resident frames, calls back to back; "chain" reports the chain kernel from
+          device events, cpu_baseline the oracle at the same qp.  --host-coder / --device-coder
+          select the older coders.  Parity unpinned for qp > 0.
 
 Prints ONE JSON line on rank 0.
 """

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
 // chain: lane = frame
 // ---------------------------------------------------------------------------------------------
 // One workgroup = two wavefronts over the same 64 frames (lane = frame).  A lone wavefront issues a
-// vector instruction only every ~6.5 cycles, dependent or not, so the step is split by what the
+// vector instruction only every ~8 cycles (one issue window in two), dependent or not, so the step is split by what the
 // next symbol needs: wavefront 0 runs the range recurrence alone (rng -> u, d, next rng) and hands
 // (u, d) of every symbol to wavefront 1 through a ring of tiles in LDS; wavefront 1 (another SIMD
 // of the CU) turns them into the code words.  Neither ever waits for the other in steady state:
@@ -346,7 +346,7 @@ typedef unsigned short lc_us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t lc_recur(uint32_t &rng, uint32_t lo, uint32_t ft)
 {
-    // daala_entropy.c:362-378 in as few instructions as possible (a lone wavefront pays ~6.5 cycles
+    // daala_entropy.c:362-378 in as few instructions as possible (a lone wavefront pays ~8 cycles
     // for each, dependent or not).  The reference scales fl, fh, ft by two when
     // rng - ft >= ft; with t = rng - ft and x = t - ft that is x >= 0 and then d = rng - 2 ft = x,
     // else d = t: d = min(t, x) as unsigned numbers.  g = sat(2 d - ft') with ft' = rng - d is

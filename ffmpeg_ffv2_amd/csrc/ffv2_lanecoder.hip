@@ -353,18 +353,26 @@ __device__ __forceinline__ uint32_t lc_recur(uint32_t &rng, uint32_t lo, uint32_
     // sat(3 d - rng).  Scaling needs ft < 32768, so fh << 1 < 65536 and both halves of `lo` shift in
     // one go; the maps of fl and fh then run as one packed 16-bit computation (every term is at
     // most rng < 65536).
-    const uint32_t t = rng - ft, x = t - ft;
+    const uint32_t t = rng - ft;
+    // x = t - ft and sc = 1 - borrow (the scale-by-two case) from one 64-bit subtraction: sub, sub-with-borrow
+    const unsigned long long w = ((1ull << 32) | t) - ft;
+    const uint32_t x = (uint32_t)w, sc = (uint32_t)(w >> 32);
     const uint32_t d = t < x ? t : x;
     const uint32_t g = __builtin_elementwise_sub_sat(3u * d, rng);
-    const uint32_t los = lo << (1u - (x >> 31));
+    const uint32_t los = lo << sc;
     const lc_us2 P = __builtin_bit_cast(lc_us2, los);
     const lc_us2 G = { (unsigned short)g, (unsigned short)g }, D = { (unsigned short)d, (unsigned short)d };
     const lc_us2 B = __builtin_elementwise_sub_sat(P, G) >> (lc_us2){ 1, 1 };
-    const lc_us2 U = P + __builtin_elementwise_min(P, G) + __builtin_elementwise_min(B, D);
-    const uint32_t u = U.x, r = (uint32_t)U.y - u;                    // 1 <= r < 65536
+    // the three terms of each half add up to at most rng < 65536: no carry leaves the low half, so
+    // the sums are plain 32-bit additions
+    const uint32_t Uw = los + __builtin_bit_cast(uint32_t, __builtin_elementwise_min(P, G))
+                            + __builtin_bit_cast(uint32_t, __builtin_elementwise_min(B, D));
+    const lc_us2 U = __builtin_bit_cast(lc_us2, Uw);
+    const uint32_t r = (uint32_t)U.y - (uint32_t)U.x;                 // 1 <= r < 65536
     const uint32_t dd = (uint32_t)__builtin_clz(r) - 16u;              // 16 - ilog(r), :107-151
     rng = r << dd;
-    return u | (dd << 16);                                             // u <= rng < 65536
+    // u (low half of U, u <= rng < 65536) and the shift in one word: bytes 0, 1 of U, byte 0 of dd, zero
+    return __builtin_amdgcn_perm(dd, __builtin_bit_cast(uint32_t, U), 0x0c040100u);
 }
 
 // State of one frame's code: where the next symbol's offset lands: bit `o` of word `woff` (the

@@ -163,7 +163,7 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  * is one dependent chain per frame (ffv2enc.c:461,466), so the device codes many frames side by
  * side, one per lane of a wavefront, and does the rest (CDF rows as prefix counts, raw bits,
  * carry propagation) data-parallel.  Throughput grows with the frames in flight until the other
- * kernels bound it; a call takes at least one frame's chain (about 75 ns per symbol).
+ * kernels bound it; a call takes at least one frame's chain (about 73 ns per symbol).
  *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call
  *                      (ffv2amd_lanecoder_bytes_per_frame() each: 84 MB per 1080p frame with the
  *                      default packet_cap and two calls in flight);

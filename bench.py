@@ -188,7 +188,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 200 (qp 0), 6 with --qp on the device coder")
+    ap.add_argument("--steps", type=int, default=None, help="default 200 (qp 0), 10 with --qp on the device coder")
     ap.add_argument("--warmup", type=int, default=None, help="default 50 (qp 0), 1 with --qp on the device coder")
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--frames-per-step", type=int, default=8)
@@ -223,7 +223,7 @@ def main():
     args = ap.parse_args()
     lane_mode = args.qp > 0 and not args.host_coder and not args.device_coder
     if args.steps is None:
-        args.steps = 6 if lane_mode else 200
+        args.steps = 10 if lane_mode else 200
     if args.warmup is None:
         args.warmup = 1 if lane_mode else 50
 

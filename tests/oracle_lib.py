@@ -59,7 +59,8 @@ class Oracle:
     def encode(self, frame, pix_fmt, qp=0, W=None):
         frame, data, ls = self._planes(frame)
         P, H, Wd = frame.shape
-        cap = 64 + 64 * frame.size
+        # a 64x64 block-plane codes to at most ~2 KB at qp 64, however small the picture
+        cap = 64 + 64 * frame.size + 2200 * P * ((H + 63) // 64) * ((Wd + 63) // 64)
         out = np.zeros(cap, np.uint8)
         size = C.c_size_t(0)
         wp = None

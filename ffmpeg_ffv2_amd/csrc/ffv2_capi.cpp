@@ -1250,7 +1250,10 @@ int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t pack
         lanecoder_free(e);
     }
     const int r = lanecoder_alloc(e, frames_in_flight, packet_cap, calls_in_flight);
-    if (r < 0) lanecoder_free(e);
+    if (r < 0) {
+        lanecoder_free(e);
+        (void)hipGetLastError();                                  // a refused hipMalloc must not surface in the next launch check
+    }
     return r;
 }
 

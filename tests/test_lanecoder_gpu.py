@@ -227,3 +227,18 @@ def test_lanecoder_frame_with_out_of_depth_samples_fails_alone(oracle):
     for i in (0, 1, 3):
         assert pk[i, : sizes[i]].tobytes() == oracle.encode(frames[i], fmt, qp=qp), i
     enc.close()
+
+
+def test_lanecoder_open_beyond_hbm_is_refused_cleanly(oracle):
+    """More frames in flight than HBM holds: FFV2AMD_ERR_NOMEM (-12), nothing leaks into later calls."""
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    enc = _enc(1920, 1080, "yuv444p", 1)
+    with pytest.raises(FFV2Error) as ei:
+        enc.lanecoder_open(100000)                       # 8.4 TB
+    assert ei.value.code == -12
+    frame = synth.noise(5, 3, 1080, 1920, 8)[None]
+    assert enc.encode_batch_to_host(enc.upload(frame), qp=0) == [oracle.encode(frame[0], "yuv444p")]
+    enc.lanecoder_open(1)
+    pk, sizes, status = enc.lanecoder_encode(enc.upload(frame), 16, as_arrays=True)
+    assert status[0] == 0 and pk[0, : sizes[0]].tobytes() == oracle.encode(frame[0], "yuv444p", qp=16)
+    enc.close()

@@ -590,7 +590,9 @@ struct ffv2amd_encoder {
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
-    fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(e_)); return FFV2AMD_ERR_DEVICE; } } while (0)
+    fprintf(stderr, "ffv2amd: %s failed: %s\n", #x, hipGetErrorString(e_)); \
+    (void)hipGetLastError();      /* reported here: must not surface again in a later launch check */ \
+    return FFV2AMD_ERR_DEVICE; } } while (0)
 
 // Every entry point runs on the encoder's device and leaves the calling thread's current
 // device as it found it (a host application may drive several GPUs from one thread).

@@ -110,7 +110,16 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     d = enc.upload(host_frames)
     d_frames = d.repeat((F + distinct - 1) // distinct, *([1] * (d.dim() - 1)))[:F].contiguous()
     del d
-    enc.lanecoder_open(F, args.packet_cap, args.calls_in_flight)
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    while True:                                   # fewer frames in flight if the device cannot hold the scratch
+        try:
+            enc.lanecoder_open(F, args.packet_cap, args.calls_in_flight)
+            break
+        except FFV2Error as ex:
+            if ex.code != -12 or F <= 64:
+                raise
+            F = max(64, F // 2 // 64 * 64)
+            d_frames = d_frames[:F]
     def finish():
         if not args.strided_packets:
             return enc.lanecoder_finish_packed()

@@ -13,6 +13,10 @@ step    : one ffv2amd_encode_batch_device call = T-stage kernel + E-stage kernel
 N > 1   : frames are independent (no inter-frame state, ffv2enc.c:461-469), so
           each rank encodes its own frames: weak scaling, no data-path collective;
           RCCL is used only for the barrier and the max-over-ranks time.
+          `--gpus N` without an outer torchrun (WORLD_SIZE unset) starts the N ranks
+          itself -- python -m torch.distributed.run as a child process, created before
+          anything touches the GPU -- and passes rank 0's JSON line through; under an
+          outer torchrun WORLD_SIZE rules.
 --qp N  : (not the BASELINE metric) the qp > 0 path with the whole entropy coder on the
           device, the range coder's serial chain running one frame per lane over many
           frames in flight (ffv2_lanecoder.hip): a step is one call over --frames-in-flight
@@ -46,23 +50,42 @@ PREROLL_GROUP, PREROLL_MAX = 10, 150
 EVENT_PERIOD = 4
 
 
-def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pinned, barrier):
+def yuv420_of(frame):
+    """A yuv420p* frame made of a synthetic 4:4:4 one: its luma, its chroma planes decimated."""
+    return [np.ascontiguousarray(frame[0]), np.ascontiguousarray(frame[1][::2, ::2]), np.ascontiguousarray(frame[2][::2, ::2])]
+
+
+def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pinned, barrier, yuv420=False):
     """Host frames in, host packets out through the asynchronous ring (ffv2amd_ring_*): the
-    metric as SURVEY.md 8(d) words it, PCIe included.  Returns (seconds, packets, bytes per frame)."""
+    metric as SURVEY.md 8(d) words it, PCIe included.  yuv420: the literal BASELINE pixel format
+    (ffv2amd_ring_send_420: half the bytes over PCIe, chroma up-converted on the device).
+    Returns (seconds, packets, bytes per frame)."""
     enc = FFV2Encoder(W, H, fmt, device=local, max_batch=1)
     enc.ring_open(depth)
     nsrc = host_frames.shape[0]
-    if pinned:
-        src = enc.pinned_frames(nsrc)
-        src[:] = host_frames
+    if yuv420:
+        src = [yuv420_of(f) for f in host_frames]
+        if pinned:
+            pool = enc.pinned_frames_420(nsrc)
+            for dst, planes in zip(pool, src):
+                for d, a in zip(dst, planes):
+                    d[:] = a
+            src = pool
+        frame_bytes = sum(a.shape[0] * a.shape[1] for a in src[0]) * enc.dtype.itemsize
+        send = lambda n: enc.ring_send_420(*src[n % nsrc], tag=n, pinned=pinned)
     else:
-        src = host_frames
-    frame_bytes = enc.info.planes * enc.info.width * enc.info.height * enc.dtype.itemsize
+        if pinned:
+            src = enc.pinned_frames(nsrc)
+            src[:] = host_frames
+        else:
+            src = host_frames
+        frame_bytes = enc.info.planes * enc.info.width * enc.info.height * enc.dtype.itemsize
+        send = lambda n: enc.ring_send(src[n % nsrc], tag=n, pinned=pinned)
 
     def run(n):
         packets, sent = [], 0
         while len(packets) < n:
-            while sent < n and enc.ring_send(src[sent % nsrc], tag=sent, pinned=pinned):
+            while sent < n and send(sent):
                 sent += 1
             tag, pk = enc.ring_receive(wait=True)
             assert tag == len(packets), "ring delivered out of order"
@@ -194,6 +217,24 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """--gpus N with no outer launcher: one rank per GPU through torch.distributed.run, started as a
+    CHILD process (a process that has touched the GPU must never exec; nothing here has touched it:
+    `import torch` does not, torch.cuda.device_count() does not on this image).  Rank 0 prints the
+    JSON line on the inherited stdout; our exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,7 +246,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="E-stage of step n on the encoder's own stream, overlapping the T-stage of step n+1 "
-                         "(measured: ~1 % more Mpix/s, but the T-stage timing then includes the overlap)")
+                         "(measured: ~1 %% more Mpix/s, but the T-stage timing then includes the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--device-coder", action="store_true",
                     help="with --qp: the adaptive range coder on the device (one wavefront per frame) instead of host threads")
@@ -213,6 +254,8 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-frames-in / host-packets-out phase")
     ap.add_argument("--host-frames", type=int, default=48, help="frames per rank in the host-boundary phase")
     ap.add_argument("--ring-depth", type=int, default=4)
+    ap.add_argument("--steady-seconds", type=float, default=2.0,
+                    help="untimed steady-state loops after the timed region (0 = skip)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="with --qp: the many-frames-in-flight device coder (ffv2_lanecoder.hip, one frame per lane of the "
                          "range chain); a step is one call over this many device-resident frames.  Default: what "
@@ -236,13 +279,21 @@ def main():
     if args.warmup is None:
         args.warmup = 1 if lane_mode else 50
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
     # one rank per GPU; FFV2_BENCH_BACKEND=gloo lets several ranks share the single GPU
     # of a development box to rehearse the N > 1 control path (never used for numbers)
     backend = os.environ.get("FFV2_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks need %d GPUs, this node has %d (FFV2_BENCH_BACKEND=gloo rehearses the control "
+                 "path with ranks sharing GPUs; its numbers mean nothing)" % (world, world, torch.cuda.device_count()))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -367,7 +418,10 @@ def main():
     # Kernel timing with HIP events on the launch stream, on every EVENT_PERIOD-th step of the timed
     # region: a pair of timing events around each kernel of every step costs 3 % of the step itself
     # (0.3685 vs 0.3571 ms), which would be charged to `value`.
-    enc.profile(EVENT_PERIOD if args.steps >= 2 * EVENT_PERIOD else 1)
+    # (A run of up to 32 steps -- the driver's -- times every step: 20 samples instead of 5 are worth the
+    # 3 %; `steady_state` below discloses the same launch with and without the events.)
+    period = EVENT_PERIOD if args.steps > 32 else 1
+    enc.profile(period)
     enc.profile_read()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -376,8 +430,45 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    t_ms, e_ms, launches = enc.profile_read()
+    t_ms, e_ms, launches, t_lo, t_hi = enc.profile_read_ex()
     enc.profile(False)
+
+    # ---- steady state, untimed (not part of `value`): the same launch back to back for
+    # --steady-seconds, first with timing events around every kernel (mean / min / max of the
+    # T-stage over hundreds of launches), then without any (wall clock per step: what the events
+    # cost).  Also keeps the GPU busy long enough for an outside observer to see it.
+    steady = None
+    if args.steady_seconds > 0:
+        steady = {}
+        enc.profile(1)
+        enc.profile_read()
+        s0, acc = time.perf_counter(), [0.0, 0.0, 0, None, None]
+        while time.perf_counter() - s0 < args.steady_seconds / 2:
+            for i in range(100):
+                enc.encode_batch_device(d_frames, out=outs[i & 1], stream=stream)
+            enc.flush(stream)
+            tt_, ee_, nn_, lo_, hi_ = enc.profile_read_ex()
+            acc[0] += tt_; acc[1] += ee_; acc[2] += nn_
+            acc[3] = lo_ if acc[3] is None else min(acc[3], lo_)
+            acc[4] = hi_ if acc[4] is None else max(acc[4], hi_)
+        torch.cuda.synchronize()
+        wall_ev = (time.perf_counter() - s0) / max(acc[2], 1)
+        enc.profile(False)
+        s0, n_plain = time.perf_counter(), 0
+        while time.perf_counter() - s0 < args.steady_seconds / 2:
+            for i in range(100):
+                enc.encode_batch_device(d_frames, out=outs[i & 1], stream=stream)
+            enc.flush(stream)
+            torch.cuda.synchronize()
+            n_plain += 100
+        wall_plain = (time.perf_counter() - s0) / max(n_plain, 1)
+        steady = {"launches_timed": acc[2], "kernel_ms_mean": round(acc[0] / max(acc[2], 1), 4),
+                  "kernel_ms_min": round(acc[3] or 0.0, 4), "kernel_ms_max": round(acc[4] or 0.0, 4),
+                  "estage_ms_mean": round(acc[1] / max(acc[2], 1), 4),
+                  "ms_per_step_with_events": round(wall_ev * 1e3, 4),
+                  "launches_untimed": n_plain, "ms_per_step_without_events": round(wall_plain * 1e3, 4),
+                  "what": "untimed loops after the timed region, same launch back to back (groups of 100, one "
+                          "host synchronisation per group), this rank"}
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -391,7 +482,7 @@ def main():
     # fresh host frames through the asynchronous ring (H2D inside the timed region), then the
     # packets are gathered in frame order on rank 0 (RCCL when N > 1).  Reported beside `value`,
     # never as `value`.
-    hb = None
+    hb, hb420_first = None, None
     if not args.no_host_boundary:
         try:
             from ffmpeg_ffv2_amd import fanout
@@ -425,6 +516,25 @@ def main():
             rate = h2d_rate(dev, frame_bytes)
             hb["h2d_copy_GBs"] = round(rate, 2)
             hb["pinned_fraction_of_h2d_copy_rate"] = round(hb["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
+            # the literal BASELINE pixel format: yuv420p* frames in host memory (half the PCIe bytes of
+            # the 4:4:4 restatement), up-converted on the device as the ffmpeg tool's auto-inserted
+            # bicubic scale filter does, then the same T/E-stage.  Parity unpinned (no libswscale here).
+            if fmt.startswith("yuv444p"):
+                y4 = {}
+                for name, pinned in [("pinned", True)] + ([("pageable", False)] if world == 1 else []):
+                    dt, pk420, fb420 = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
+                                                     pinned, barrier, yuv420=True)
+                    if world > 1:
+                        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        dt = float(tt.item())
+                    y4[name] = {"Mpix_s": round(world * nf * W * H / dt / 1e6, 1), "ms_per_frame_per_gpu": round(dt / nf * 1e3, 4),
+                                "h2d_GBs_per_gpu": round(nf * fb420 / dt / 1e9, 2)}
+                y4["pix_fmt"] = fmt.replace("444", "420")
+                y4["speedup_over_444"] = round(y4["pinned"]["Mpix_s"] / hb["pinned"]["Mpix_s"], 3)
+                y4["pinned_fraction_of_h2d_copy_rate"] = round(y4["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
+                hb["yuv420"] = y4
+                hb420_first = (pk420[0], yuv420_of(host_frames[0]))
             hb["frames_per_gpu"] = nf
             hb["ring_depth"] = args.ring_depth
             hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "
@@ -484,9 +594,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms_avg": round(t_kernel_ms, 4),
                          "estage_ms_avg": round(e_ms / max(launches, 1), 4),
+                         "kernel_ms_min": round(t_lo, 4), "kernel_ms_max": round(t_hi, 4),
                          "launches_timed": launches,
-                         "timed_every_nth_step": EVENT_PERIOD if args.steps >= 2 * EVENT_PERIOD else 1},
+                         "timed_every_nth_step": period},
         }
+        if steady is not None:
+            result["steady_state"] = steady
+            if steady["launches_timed"]:
+                result["steady_state"]["roofline_frac"] = round(
+                    alg_bytes / (steady["kernel_ms_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if hb is not None:
             result["host_boundary"] = hb
         if world == 1 and not args.no_cpu_baseline:
@@ -518,6 +634,11 @@ def main():
             result["cpu_baseline"]["all_cores"] = {"value": round(nthr * W * H / tall / 1e6, 1), "unit": "Mpix/s",
                                                    "cores": nthr, "sample": "one 4K frame per thread" if W == 3840
                                                    else "one frame per thread"}
+            if hb420_first is not None and "yuv420" in (hb or {}):
+                pk0, (y0, u0, v0) = hb420_first
+                ok420 = oracle.encode(oracle.sws_420_to_444(y0, u0, v0, depth), fmt) == pk0
+                hb["yuv420"]["packet0_matches_oracle_convert_then_encode"] = bool(ok420)
+                ok = ok and ok420
             if not ok:
                 result["error"] = "GPU packets differ from the CPU oracle"
         print(json.dumps(result))

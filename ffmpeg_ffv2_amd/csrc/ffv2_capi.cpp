@@ -515,7 +515,7 @@ struct ffv2amd_encoder {
     int seq_pb = 0;                      // hand-off buffer set of the call being issued
     std::vector<EvTriple> ev_pool;       // reused
     size_t ev_used = 0;
-    double prof_t = 0, prof_e = 0;
+    double prof_t = 0, prof_e = 0, prof_tmin = 0, prof_tmax = 0;   // sums (and T-stage extremes) of drained events
     int prof_n = 0;
     // qp > 0 pipeline (ffv2amd_qp_submit / _finish): two sets, so that the host coder of batch n
     // runs while the GPU works on batch n+1
@@ -541,6 +541,10 @@ struct ffv2amd_encoder {
     size_t q_stream_stride = 0;
     hipStream_t q_copy = nullptr;
     unsigned q_sub = 0, q_fin = 0;
+    // host frames through that pipeline (ffv2amd_qp_send_frame / _receive_packet): one frame per batch
+    uint8_t *qh_frame[2] = { nullptr, nullptr }, *qd_frame[2] = { nullptr, nullptr };
+    int32_t *qd_w[2] = { nullptr, nullptr };
+    int64_t q_tag[2] = { 0, 0 };
     // 4:2:0 -> 4:4:4 front end (ffv2amd_*_420)
     FFV2Upconv *upconv = nullptr;
     bool upconv_tried = false;
@@ -552,6 +556,7 @@ struct ffv2amd_encoder {
         uint32_t *d_meta = nullptr, *h_meta = nullptr;      // [0] size, [1] status
         uint32_t *d_codes = nullptr, *d_bitcnt = nullptr;
         int32_t  *d_w = nullptr;
+        uint8_t  *d_c420 = nullptr;                         // U, V of a 4:2:0 frame, rows c_pitch apart (ring_send_420)
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_meta = nullptr;
         int64_t tag = 0;
     };
@@ -691,6 +696,10 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
         if (q.h_pk_status) (void)hipHostFree(q.h_pk_status);
     }
     if (e->q_copy) { (void)hipStreamSynchronize(e->q_copy); (void)hipStreamDestroy(e->q_copy); }
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(e->qd_frame[k]); (void)hipFree(e->qd_w[k]);
+        if (e->qh_frame[k]) (void)hipHostFree(e->qh_frame[k]);
+    }
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status); (void)hipFree(e->d_err);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
@@ -851,9 +860,9 @@ int ffv2amd_encode_batch_device(ffv2amd_encoder *e, int nframes, const void *d_f
     if (e->profiling > 0 && (e->prof_calls++ % (unsigned)e->profiling) == 0) {
         if (e->ev_used == e->ev_pool.size()) {
             if (e->ev_pool.size() >= 8192) {                 // drain before growing without bound
-                double t, x; int n;
-                ffv2amd_profile_read(e, &t, &x, &n);
-                e->prof_t += t; e->prof_e += x; e->prof_n += n;
+                double t, x, lo, hi; int n;
+                ffv2amd_profile_read_ex(e, &t, &x, &n, &lo, &hi);
+                e->prof_t = t; e->prof_e = x; e->prof_n = n; e->prof_tmin = lo; e->prof_tmax = hi;
             } else {
                 ffv2amd_encoder::EvTriple t{};
                 HIPCHK(hipEventCreate(&t.a)); HIPCHK(hipEventCreate(&t.b)); HIPCHK(hipEventCreate(&t.c));
@@ -930,24 +939,34 @@ int ffv2amd_profile_enable(ffv2amd_encoder *e, int on)
     return FFV2AMD_OK;
 }
 
-int ffv2amd_profile_read(ffv2amd_encoder *e, double *tstage_ms, double *estage_ms, int *launches)
+int ffv2amd_profile_read_ex(ffv2amd_encoder *e, double *tstage_ms, double *estage_ms, int *launches,
+                            double *tstage_min_ms, double *tstage_max_ms)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
-    double t = e->prof_t, x = e->prof_e;
+    double t = e->prof_t, x = e->prof_e, lo = e->prof_tmin, hi = e->prof_tmax;
     int n = e->prof_n;
     for (size_t i = 0; i < e->ev_used; i++) {
         float ms = 0;
         HIPCHK(hipEventSynchronize(e->ev_pool[i].c));
         HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b)); t += ms;
+        if (n == 0 || ms < lo) lo = ms;
+        if (n == 0 || ms > hi) hi = ms;
         HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].d, e->ev_pool[i].c)); x += ms;
         n++;
     }
     e->ev_used = 0;
-    e->prof_t = e->prof_e = 0; e->prof_n = 0;
+    e->prof_t = e->prof_e = e->prof_tmin = e->prof_tmax = 0; e->prof_n = 0;
     if (tstage_ms) *tstage_ms = t;
     if (estage_ms) *estage_ms = x;
     if (launches) *launches = n;
+    if (tstage_min_ms) *tstage_min_ms = lo;
+    if (tstage_max_ms) *tstage_max_ms = hi;
     return FFV2AMD_OK;
+}
+
+int ffv2amd_profile_read(ffv2amd_encoder *e, double *tstage_ms, double *estage_ms, int *launches)
+{
+    return ffv2amd_profile_read_ex(e, tstage_ms, estage_ms, launches, nullptr, nullptr);
 }
 
 int ffv2amd_encode_frame(ffv2amd_encoder *e,
@@ -1584,6 +1603,69 @@ int ffv2amd_qp_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t packet_stri
     return FFV2AMD_OK;
 }
 
+// Host frames through the qp > 0 pipeline, one frame per batch: the shape of avcodec_send_frame /
+// avcodec_receive_packet (encode.c:420,449) for global_quality > 0.  send: the caller's rows are
+// gathered into a page-locked frame, copied over on the encoder's stream and followed there by
+// T-stage, PVQ search and symbol compaction (ffv2amd_qp_submit); at most two frames in flight.
+// receive: the oldest frame's range coder on the calling thread (ffv2amd_qp_finish) -- the GPU
+// meanwhile works on the frame sent after it.
+int ffv2amd_qp_send_frame(ffv2amd_encoder *e, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                          int qp, const int32_t *W, int64_t tag)
+{
+    if (!e || !data || !linesize) return FFV2AMD_ERR_INVAL;
+    if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
+    const ffv2amd_info &in = e->info;
+    for (int p = 0; p < in.planes; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    if (e->q_sub - e->q_fin >= 2) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const int k = (int)(e->q_sub & 1u);
+    if (!e->qd_frame[k]) {
+        HIPCHK(hipMalloc(&e->qd_frame[k], in.frame_stride));
+        HIPCHK(hipMalloc(&e->qd_w[k], sizeof(int32_t) * in.block_planes));
+        HIPCHK(hipHostMalloc(&e->qh_frame[k], in.frame_stride, hipHostMallocDefault));
+        memset(e->qh_frame[k], 0, in.frame_stride);
+    }
+    const size_t row_bytes = (size_t)in.width * (in.depth > 8 ? 2 : 1);
+    for (int p = 0; p < in.planes; p++) {
+        uint8_t *dst = e->qh_frame[k] + (size_t)p * in.plane_stride;
+        for (int y = 0; y < in.height; y++)
+            memcpy(dst + (size_t)y * in.row_pitch, data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
+        HIPCHK(hipMemcpyAsync(e->qd_frame[k] + (size_t)p * in.plane_stride, dst, in.row_pitch * (size_t)in.height,
+                              hipMemcpyHostToDevice, e->stream));
+    }
+    const int32_t *dW = nullptr;
+    if (W) {
+        // W may be pageable and reused by the caller: this copy is complete when the call returns
+        HIPCHK(hipMemcpyAsync(e->qd_w[k], W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        dW = e->qd_w[k];
+    }
+    const int r = ffv2amd_qp_submit(e, 1, e->qd_frame[k], qp, dW);
+    if (r < 0) return r;
+    e->q_tag[k] = tag;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qp_receive_packet(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag)
+{
+    if (!e || !out || !out_size) return FFV2AMD_ERR_INVAL;
+    if (e->q_fin == e->q_sub) return FFV2AMD_ERR_AGAIN;
+    const int k = (int)(e->q_fin & 1u);
+    if (e->qset[k].nframes != 1) return FFV2AMD_ERR_INVAL;      // the oldest batch came from ffv2amd_qp_submit
+    uint32_t sz = 0;
+    int32_t st = 0;
+    if (tag) *tag = e->q_tag[k];
+    const int r = ffv2amd_qp_finish(e, out, out_cap, &sz, &st);
+    if (r < 0) return r;
+    if (st < 0) return st;                                       // the frame has left the pipeline all the same
+    *out_size = sz;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qp_pending(const ffv2amd_encoder *e) { return e ? (int)(e->q_sub - e->q_fin) : 0; }
+
 int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_frames,
                                  int qp, const int32_t *d_W,
                                  uint8_t *h_packets, size_t packet_stride,
@@ -1690,7 +1772,7 @@ void ffv2amd_ring_close(ffv2amd_encoder *e)
         if (st) (void)hipStreamSynchronize(st);
     for (auto &r : e->ring) {
         (void)hipFree(r.d_frame); (void)hipFree(r.d_pkt); (void)hipFree(r.d_meta);
-        (void)hipFree(r.d_codes); (void)hipFree(r.d_bitcnt); (void)hipFree(r.d_w);
+        (void)hipFree(r.d_codes); (void)hipFree(r.d_bitcnt); (void)hipFree(r.d_w); (void)hipFree(r.d_c420);
         if (r.h_frame) (void)hipHostFree(r.h_frame);
         if (r.h_pkt) (void)hipHostFree(r.h_pkt);
         if (r.h_meta) (void)hipHostFree(r.h_meta);
@@ -1752,45 +1834,52 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
 
 int ffv2amd_ring_pending(const ffv2amd_encoder *e) { return e ? e->ring_count : 0; }
 
-int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const ptrdiff_t linesize[4],
-                      const int32_t *W, int64_t tag, unsigned flags)
+// One plane of a frame on its way into a ring slot: `rows` rows of `row_bytes` bytes from the caller's
+// (src, linesize) to device memory (d_dst, rows pitch bytes apart); `stage` is the slot's page-locked
+// copy of it, used when the caller's memory is pageable.
+struct RingPlane {
+    const uint8_t *src;
+    ptrdiff_t linesize;
+    size_t row_bytes, pitch;
+    int rows, slices;
+    uint8_t *d_dst, *stage;
+};
+
+// H2D of the planes, then T-stage + E-stage on a compute stream (4:2:0: the chroma up-conversion in
+// front of them), then the {size, status} D2H: the body of ring_send / ring_send_420.
+static int ring_submit(ffv2amd_encoder *e, ffv2amd_encoder::RingSlot &r, const RingPlane *pl, int npl, bool chroma420,
+                       const int32_t *W, int64_t tag, unsigned flags)
 {
-    if (!e || !data || !linesize || e->ring.empty()) return FFV2AMD_ERR_INVAL;
     const ffv2amd_info &in = e->info;
-    for (int p = 0; p < in.planes; p++)
-        if (!data[p]) return FFV2AMD_ERR_INVAL;
-    if (e->ring_count == (int)e->ring.size()) return FFV2AMD_ERR_AGAIN;
-    DeviceGuard guard(e->device);
-    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
-    auto &r = e->ring[(size_t)((e->ring_head + e->ring_count) % (int)e->ring.size())];
-    const size_t row_bytes = (size_t)in.width * (in.depth > 8 ? 2 : 1);
     hipStream_t sh = e->ring_h2d;
     if (flags & FFV2AMD_FRAME_PINNED) {
         // page-locked planes: the DMA engine reads the caller's rows directly
-        for (int p = 0; p < in.planes; p++) {
-            uint8_t *dst = r.d_frame + (size_t)p * in.plane_stride;
-            if (linesize[p] == (ptrdiff_t)in.row_pitch)
-                HIPCHK(hipMemcpyAsync(dst, data[p], in.row_pitch * (size_t)(in.height - 1) + row_bytes, hipMemcpyHostToDevice, sh));
+        for (int i = 0; i < npl; i++) {
+            const RingPlane &q = pl[i];
+            if (q.linesize == (ptrdiff_t)q.pitch)
+                HIPCHK(hipMemcpyAsync(q.d_dst, q.src, q.pitch * (size_t)(q.rows - 1) + q.row_bytes, hipMemcpyHostToDevice, sh));
             else
-                HIPCHK(hipMemcpy2DAsync(dst, in.row_pitch, data[p], (size_t)linesize[p], row_bytes, (size_t)in.height,
+                HIPCHK(hipMemcpy2DAsync(q.d_dst, q.pitch, q.src, (size_t)q.linesize, q.row_bytes, (size_t)q.rows,
                                         hipMemcpyHostToDevice, sh));
         }
     } else {
         // pageable planes: gather into the slot's pinned frame in slices of rows; every slice's DMA
         // is issued as soon as it is gathered (by the pool's threads when the picture is large)
-        const int per_plane = e->ring_pool ? 4 : 1;
-        const int nsl = in.planes * per_plane;
+        int first[5] = { 0, 0, 0, 0, 0 };
+        for (int i = 0; i < npl; i++) first[i + 1] = first[i] + (e->ring_pool ? pl[i].slices : 1);
+        const int nsl = first[npl];
         hipError_t up[32];
         for (int i = 0; i < nsl; i++) up[i] = hipSuccess;
         const std::function<void(int)> slice = [&](int i) {
-            const int p = i / per_plane, k = i - p * per_plane;
-            const int y0 = (int)((long long)in.height * k / per_plane), y1 = (int)((long long)in.height * (k + 1) / per_plane);
+            int p = 0;
+            while (i >= first[p + 1]) p++;
+            const RingPlane &q = pl[p];
+            const int k = i - first[p], per = first[p + 1] - first[p];
+            const int y0 = (int)((long long)q.rows * k / per), y1 = (int)((long long)q.rows * (k + 1) / per);
             if (y1 <= y0) return;
-            const size_t off = (size_t)p * in.plane_stride + (size_t)y0 * in.row_pitch;
             for (int y = y0; y < y1; y++)
-                memcpy(r.h_frame + (size_t)p * in.plane_stride + (size_t)y * in.row_pitch,
-                       data[p] + (ptrdiff_t)y * linesize[p], row_bytes);
-            up[i] = hipMemcpyAsync(r.d_frame + off, r.h_frame + off, (size_t)(y1 - y0) * in.row_pitch,
+                memcpy(q.stage + (size_t)y * q.pitch, q.src + (ptrdiff_t)y * q.linesize, q.row_bytes);
+            up[i] = hipMemcpyAsync(q.d_dst + (size_t)y0 * q.pitch, q.stage + (size_t)y0 * q.pitch, (size_t)(y1 - y0) * q.pitch,
                                    hipMemcpyHostToDevice, sh);
         };
         if (e->ring_pool) {
@@ -1808,6 +1897,9 @@ int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const pt
     HIPCHK(hipEventRecord(r.ev_h2d, sh));
     hipStream_t sc = e->ring_comp[e->ring_seq++ & 1u];
     HIPCHK(hipStreamWaitEvent(sc, r.ev_h2d, 0));
+    if (chroma420)
+        HIPCHK(ffv2_launch_upconv_chroma(e->upconv, e->geom, 1, r.d_c420, pl[1].pitch, pl[1].pitch * (size_t)pl[1].rows, 0,
+                                         r.d_frame, sc));
     int rc = launch_encode_qp0(e, 1, r.d_frame, dW, r.d_pkt, in.packet_cap, r.d_meta, (int32_t *)(r.d_meta + 1),
                                r.d_codes, r.d_bitcnt, nullptr, sc, sc, nullptr, (int32_t *)(r.d_meta + 2));
     if (rc < 0) return rc;
@@ -1818,6 +1910,54 @@ int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const pt
     r.tag = tag;
     e->ring_count++;
     return FFV2AMD_OK;
+}
+
+int ffv2amd_ring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                      const int32_t *W, int64_t tag, unsigned flags)
+{
+    if (!e || !data || !linesize || e->ring.empty()) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    for (int p = 0; p < in.planes; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    if (e->ring_count == (int)e->ring.size()) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    auto &r = e->ring[(size_t)((e->ring_head + e->ring_count) % (int)e->ring.size())];
+    RingPlane pl[4];
+    for (int p = 0; p < in.planes; p++)
+        pl[p] = RingPlane{ data[p], linesize[p], (size_t)in.width * (in.depth > 8 ? 2 : 1), in.row_pitch, in.height, 4,
+                           r.d_frame + (size_t)p * in.plane_stride, r.h_frame + (size_t)p * in.plane_stride };
+    return ring_submit(e, r, pl, in.planes, false, W, tag, flags);
+}
+
+// 4:2:0 frames through the ring (SURVEY.md 8(f) rank 4 at the asynchronous boundary): half the PCIe
+// bytes of the 4:4:4 form.  Luma goes straight into plane 0 of the slot's device frame, the two
+// chroma planes into a small staging area, and the up-conversion (ffv2_upconv.hip) runs on the
+// frame's compute stream in front of its T-stage.
+int ffv2amd_ring_send_420(ffv2amd_encoder *e, const uint8_t *const data[3], const ptrdiff_t linesize[3],
+                          const int32_t *W, int64_t tag, unsigned flags)
+{
+    if (!e || !data || !linesize || e->ring.empty() || !data[0] || !data[1] || !data[2]) return FFV2AMD_ERR_INVAL;
+    if (e->ring_count == (int)e->ring.size()) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    int rc = upconv_ready(e);
+    if (rc < 0) return rc;
+    const ffv2amd_info &in = e->info;
+    const size_t bps = in.depth > 8 ? 2 : 1;
+    const int cw = (in.width + 1) >> 1, ch = (in.height + 1) >> 1;
+    const size_t c_pitch = align_up((size_t)cw * bps, 128);
+    auto &r = e->ring[(size_t)((e->ring_head + e->ring_count) % (int)e->ring.size())];
+    if (!r.d_c420) HIPCHK(hipMalloc(&r.d_c420, 2 * c_pitch * (size_t)ch));
+    // pinned staging of a pageable frame: luma in plane 0 of the slot's host frame, U and V behind it
+    // ((h + 1) * c_pitch <= 2 * h * row_pitch: they fit planes 1 and 2)
+    uint8_t *cst = r.h_frame + in.plane_stride;
+    RingPlane pl[3] = {
+        RingPlane{ data[0], linesize[0], (size_t)in.width * bps, in.row_pitch, in.height, 4, r.d_frame, r.h_frame },
+        RingPlane{ data[1], linesize[1], (size_t)cw * bps, c_pitch, ch, 1, r.d_c420, cst },
+        RingPlane{ data[2], linesize[2], (size_t)cw * bps, c_pitch, ch, 1, r.d_c420 + c_pitch * (size_t)ch, cst + c_pitch * (size_t)ch },
+    };
+    return ring_submit(e, r, pl, 3, true, W, tag, flags);
 }
 
 int ffv2amd_ring_receive(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag, int wait)

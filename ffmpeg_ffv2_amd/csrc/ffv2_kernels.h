@@ -78,6 +78,9 @@ void ffv2_upconv_destroy(FFV2Upconv *u);
 size_t ffv2_upconv_src_frame_bytes(int w, int h, int depth);
 hipError_t ffv2_launch_upconv(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src,
                               size_t src_frame_stride, uint8_t *dst, hipStream_t s);
+hipError_t ffv2_launch_upconv_chroma(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src_u,
+                                     size_t c_pitch, size_t c_plane_stride, size_t src_frame_stride, uint8_t *dst,
+                                     hipStream_t s);
 
 // qp > 0 entropy coder on the device (ffv2_rangecoder.hip): one wavefront per frame
 struct FFV2RangeCoderArgs {

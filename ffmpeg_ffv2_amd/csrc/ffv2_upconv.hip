@@ -14,10 +14,19 @@
 //                   8 bit: round = 64 << 12, shift 19 (yuv2planeX_8_c, no dither for 8-bit sources)
 //                   deeper: round = 1 << (shift-1), shift = 27 - depth   (output.c:333-393)
 // PARITY UNPINNED: no libswscale binary or vector exists here; checked against
-// oracle/ffv2_swscale_oracle.c, an independent restatement of the same reference code.
+// oracle/ffv2_swscale_oracle.c.  build_axis() below RESTATES initFilter()'s integer steps (they must
+// be the same steps for the tables to be bit-exact), and so does the oracle: the coefficient tables
+// are effectively compared with a second writing of the same derivation, only the device arithmetic
+// of the two 4-tap passes is checked independently.
 //
 // Host part: the coefficient tables (integer arithmetic of initFilter, once per geometry).
-// Device part: one thread per output chroma sample and plane; luma rows are copied.
+// Device part: ffv2_upconv_tile_kernel -- a workgroup owns a 128 x 32 tile of one output chroma
+// plane: the source patch it needs (<= 24 x 80 samples) goes to LDS, the horizontal pass runs once
+// per source row into a 15-bit LDS intermediate (what swscale keeps between its two passes), the
+// vertical pass reads it back as 16-byte rows and stores 8 samples per lane.  6.4 multiplies per
+// output sample instead of the 20 of the one-thread-per-sample kernel, which stays as the fallback
+// for geometries whose patch would not fit.  Luma is the identity: rows copied (or, in the frame
+// ring, sent by the DMA engine straight into plane 0).
 #include "ffv2_kernels.h"
 
 #include <stdlib.h>
@@ -145,9 +154,10 @@ bool build_axis(AxisFilter &out, int n, int one)
 }
 
 struct UpArgs {
-    const uint8_t *src;        // [nframes][src_frame_stride]: Y (w x h), U, V (cw x ch), tightly packed rows
+    const uint8_t *src;        // U plane of frame 0; V at + c_plane_stride, frame f at + f * src_frame_stride
     uint8_t *dst;              // [nframes][frame_stride]: the encoder's 4:4:4 layout
-    size_t src_frame_stride, frame_stride, plane_stride, row_pitch;
+    size_t src_frame_stride, c_plane_stride, c_pitch;     // bytes
+    size_t frame_stride, plane_stride, row_pitch;
     int w, h, cw, ch, depth, htaps, vtaps;
     const int16_t *hf, *vf;    // [w][UP_TAPS], [h][UP_TAPS]
     const int32_t *hp, *vp;
@@ -159,8 +169,7 @@ __global__ __launch_bounds__(256) void ffv2_upconv_kernel(const UpArgs a)
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const int p = 1 + (int)(blockIdx.z & 1u), f = (int)(blockIdx.z >> 1);
     if (x >= a.w) return;
-    const size_t ybytes = (size_t)a.w * a.h * BPS, cbytes = (size_t)a.cw * a.ch * BPS;
-    const uint8_t *sp = a.src + (size_t)f * a.src_frame_stride + ybytes + (size_t)(p - 1) * cbytes;
+    const uint8_t *sp = a.src + (size_t)f * a.src_frame_stride + (size_t)(p - 1) * a.c_plane_stride;
     const int hp = a.hp[x], vp = a.vp[y];
     int hc[UP_TAPS], vc[UP_TAPS];
 #pragma unroll
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void ffv2_upconv_kernel(const UpArgs a)
     const int vsh = BPS == 1 ? 19 : 27 - a.depth;
     int val = BPS == 1 ? 64 << 12 : 1 << (vsh - 1);
     for (int j = 0; j < a.vtaps; j++) {
-        const uint8_t *row = sp + (size_t)(vp + j) * a.cw * BPS;
+        const uint8_t *row = sp + (size_t)(vp + j) * a.c_pitch;
         int hv = 0;
         for (int k = 0; k < a.htaps; k++) {
             const int s = BPS == 1 ? row[hp + k] : reinterpret_cast<const uint16_t *>(row)[hp + k];
@@ -187,10 +196,113 @@ __global__ __launch_bounds__(256) void ffv2_upconv_kernel(const UpArgs a)
     else reinterpret_cast<uint16_t *>(dp)[x] = (uint16_t)val;
 }
 
+// ---- tiled kernel ----
+constexpr int UT_W = 128, UT_H = 32;           // output tile
+constexpr int UT_SR = 24, UT_SC = 80;          // source patch bound (rows, columns); checked on the host per geometry
+constexpr int UT_HP = UT_W + 8;                // int16 per row of the horizontal-pass buffer (272 B rows)
+
+template <int BPS>
+__global__ __launch_bounds__(256) void ffv2_upconv_tile_kernel(const UpArgs a)
+{
+    __shared__ uint16_t patch[UT_SR][UT_SC];
+    __shared__ __attribute__((aligned(16))) int16_t hbuf[UT_SR][UT_HP];
+    __shared__ int16_t vcs[UT_H][4];
+    __shared__ int vps[UT_H];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * UT_W, y0 = blockIdx.y * UT_H;
+    const int p = 1 + (int)(blockIdx.z & 1u), f = (int)(blockIdx.z >> 1);
+    const uint8_t *sp = a.src + (size_t)f * a.src_frame_stride + (size_t)(p - 1) * a.c_plane_stride;
+    const int xl = min(x0 + UT_W, a.w) - 1, yl = min(y0 + UT_H, a.h) - 1;     // last output column / row of the tile
+    const int cs0 = a.hp[x0], cs1 = min(a.hp[xl] + a.htaps, a.cw);           // source columns [cs0, cs1)
+    const int rs0 = a.vp[y0], rs1 = min(a.vp[yl] + a.vtaps, a.ch);
+    const int ncols = cs1 - cs0, nrows = rs1 - rs0;
+    // source patch -> LDS (rows of <= 80 samples; lanes read consecutive samples)
+    for (int i = t; i < nrows * UT_SC; i += 256) {
+        const int r = i / UT_SC, c = i - r * UT_SC;
+        if (c < ncols) {
+            const uint8_t *row = sp + (size_t)(rs0 + r) * a.c_pitch;
+            patch[r][c] = BPS == 1 ? row[cs0 + c] : reinterpret_cast<const uint16_t *>(row)[cs0 + c];
+        }
+    }
+    if (t < UT_H) {
+        const int y = min(y0 + t, a.h - 1);
+        vps[t] = a.vp[y] - rs0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) vcs[t][k] = a.vf[(size_t)y * UP_TAPS + k];
+    }
+    // this thread's column of the horizontal pass
+    const int xc = min(x0 + (t & (UT_W - 1)), a.w - 1);
+    const int hp = a.hp[xc] - cs0;
+    int hc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hc[k] = a.hf[(size_t)xc * UP_TAPS + k];
+    __syncthreads();
+    // horizontal pass: h = min((sum s * c) >> hsh, 32767)   (hScale8To15_c / hScale16To15_c)
+    const int hsh = BPS == 1 ? 7 : a.depth - 1;
+    for (int r = t >> 7; r < nrows; r += 2) {
+        int hv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = hp + k;
+            hv += (k < a.htaps && c < ncols ? (int)patch[r][c] : 0) * hc[k];
+        }
+        hv >>= hsh;
+        hbuf[r][t & (UT_W - 1)] = (int16_t)(hv < 32767 ? hv : 32767);
+    }
+    __syncthreads();
+    // vertical pass: 8 adjacent samples of one row per item   (yuv2planeX_8_c / yuv2planeX_10_c_template)
+    const int vsh = BPS == 1 ? 19 : 27 - a.depth;
+    const int rnd = BPS == 1 ? 64 << 12 : 1 << (vsh - 1);
+    const int hi = (1 << a.depth) - 1;
+#pragma unroll
+    for (int it = 0; it < UT_W * UT_H / 8 / 256; it++) {
+        const int id = t + 256 * it;
+        const int ty = id >> 4, xg = (id & 15) * 8;
+        const int y = y0 + ty, x = x0 + xg;
+        if (y >= a.h || x >= a.w) continue;
+        int acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = rnd;
+        const int vp = vps[ty];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = vp + j;
+            const int c = vcs[ty][j];
+            if (j < a.vtaps && r < nrows) {
+                const int4 w = *reinterpret_cast<const int4 *>(&hbuf[r][xg]);
+                const int wv[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    acc[2 * q]     += ((wv[q] << 16) >> 16) * c;
+                    acc[2 * q + 1] += (wv[q] >> 16) * c;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int v = acc[e] >> vsh;
+            acc[e] = v < 0 ? 0 : (v > hi ? hi : v);
+        }
+        // the row pitch is a multiple of 128 bytes: a whole vector may be written where the picture
+        // ends inside it (the padding behind the last sample is never read as picture)
+        uint8_t *dp = a.dst + (size_t)f * a.frame_stride + (size_t)p * a.plane_stride + (size_t)y * a.row_pitch;
+        if (BPS == 1) {
+            const uint2 o = make_uint2((uint32_t)acc[0] | ((uint32_t)acc[1] << 8) | ((uint32_t)acc[2] << 16) | ((uint32_t)acc[3] << 24),
+                                       (uint32_t)acc[4] | ((uint32_t)acc[5] << 8) | ((uint32_t)acc[6] << 16) | ((uint32_t)acc[7] << 24));
+            *reinterpret_cast<uint2 *>(dp + x) = o;
+        } else {
+            const uint4 o = make_uint4((uint32_t)acc[0] | ((uint32_t)acc[1] << 16), (uint32_t)acc[2] | ((uint32_t)acc[3] << 16),
+                                       (uint32_t)acc[4] | ((uint32_t)acc[5] << 16), (uint32_t)acc[6] | ((uint32_t)acc[7] << 16));
+            *reinterpret_cast<uint4 *>(dp + (size_t)x * 2) = o;
+        }
+    }
+}
+
 }  // namespace
 
 struct FFV2Upconv {
     int w = 0, h = 0, depth = 0, htaps = 0, vtaps = 0;
+    bool tiled = false;        // every 128 x 32 output tile's source patch fits the tiled kernel's LDS
     int16_t *d_hf = nullptr, *d_vf = nullptr;
     int32_t *d_hp = nullptr, *d_vp = nullptr;
 };
@@ -213,6 +325,25 @@ FFV2Upconv *ffv2_upconv_create(int w, int h, int depth)
     FFV2Upconv *u = new (std::nothrow) FFV2Upconv;
     if (!u) return nullptr;
     u->w = w; u->h = h; u->depth = depth; u->htaps = hx.taps; u->vtaps = vy.taps;
+    {
+        const int cw = (w + 1) >> 1, ch = (h + 1) >> 1;
+        bool fits = hx.taps <= 4 && vy.taps <= 4;
+        for (int x0 = 0; x0 < w && fits; x0 += UT_W) {
+            const int xl = (x0 + UT_W < w ? x0 + UT_W : w) - 1;
+            int c1 = hx.pos[(size_t)xl] + hx.taps;
+            if (c1 > cw) c1 = cw;
+            fits = c1 - hx.pos[(size_t)x0] <= UT_SC && hx.pos[(size_t)x0] >= 0;
+            for (int x = x0; x <= xl && fits; x++) fits = hx.pos[(size_t)x] >= hx.pos[(size_t)x0] && hx.pos[(size_t)x] <= hx.pos[(size_t)xl];
+        }
+        for (int y0 = 0; y0 < h && fits; y0 += UT_H) {
+            const int yl = (y0 + UT_H < h ? y0 + UT_H : h) - 1;
+            int r1 = vy.pos[(size_t)yl] + vy.taps;
+            if (r1 > ch) r1 = ch;
+            fits = r1 - vy.pos[(size_t)y0] <= UT_SR && vy.pos[(size_t)y0] >= 0;
+            for (int y = y0; y <= yl && fits; y++) fits = vy.pos[(size_t)y] >= vy.pos[(size_t)y0] && vy.pos[(size_t)y] <= vy.pos[(size_t)yl];
+        }
+        u->tiled = fits;
+    }
     bool ok = hipMalloc(&u->d_hf, hx.coef.size() * 2) == hipSuccess && hipMalloc(&u->d_vf, vy.coef.size() * 2) == hipSuccess &&
               hipMalloc(&u->d_hp, hx.pos.size() * 4) == hipSuccess && hipMalloc(&u->d_vp, vy.pos.size() * 4) == hipSuccess;
     ok = ok && hipMemcpy(u->d_hf, hx.coef.data(), hx.coef.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
@@ -229,6 +360,32 @@ size_t ffv2_upconv_src_frame_bytes(int w, int h, int depth)
     return ((size_t)w * h + 2 * (size_t)((w + 1) >> 1) * ((h + 1) >> 1)) * bps;
 }
 
+// chroma planes only: src_u = U plane of frame 0 (rows c_pitch bytes apart), V at + c_plane_stride,
+// the next frame at + src_frame_stride; dst = the encoder's 4:4:4 frames (planes 1 and 2 are written)
+hipError_t ffv2_launch_upconv_chroma(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src_u,
+                                     size_t c_pitch, size_t c_plane_stride, size_t src_frame_stride, uint8_t *dst,
+                                     hipStream_t s)
+{
+    const int bps = g.bytes_per_sample;
+    UpArgs a{};
+    a.src = src_u; a.dst = dst; a.src_frame_stride = src_frame_stride; a.c_plane_stride = c_plane_stride; a.c_pitch = c_pitch;
+    a.frame_stride = g.frame_stride; a.plane_stride = g.plane_stride; a.row_pitch = g.row_pitch;
+    a.w = g.width; a.h = g.height; a.cw = (g.width + 1) >> 1; a.ch = (g.height + 1) >> 1; a.depth = g.depth;
+    a.htaps = u->htaps; a.vtaps = u->vtaps; a.hf = u->d_hf; a.vf = u->d_vf; a.hp = u->d_hp; a.vp = u->d_vp;
+    static const int force_naive = getenv("FFV2AMD_UPCONV_NAIVE") ? atoi(getenv("FFV2AMD_UPCONV_NAIVE")) : 0;
+    if (u->tiled && !force_naive) {
+        const dim3 grid((unsigned)((g.width + UT_W - 1) / UT_W), (unsigned)((g.height + UT_H - 1) / UT_H), (unsigned)(2 * nframes)), block(256);
+        if (bps == 1) hipLaunchKernelGGL(ffv2_upconv_tile_kernel<1>, grid, block, 0, s, a);
+        else          hipLaunchKernelGGL(ffv2_upconv_tile_kernel<2>, grid, block, 0, s, a);
+    } else {
+        const dim3 grid((unsigned)((g.width + 255) / 256), (unsigned)g.height, (unsigned)(2 * nframes)), block(256);
+        if (bps == 1) hipLaunchKernelGGL(ffv2_upconv_kernel<1>, grid, block, 0, s, a);
+        else          hipLaunchKernelGGL(ffv2_upconv_kernel<2>, grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// tightly packed 4:2:0 frames (Y, U, V back to back) -> 4:4:4 frames
 hipError_t ffv2_launch_upconv(const FFV2Upconv *u, const FFV2Geom &g, int nframes, const uint8_t *src,
                               size_t src_frame_stride, uint8_t *dst, hipStream_t s)
 {
@@ -240,13 +397,7 @@ hipError_t ffv2_launch_upconv(const FFV2Upconv *u, const FFV2Geom &g, int nframe
                                                hipMemcpyDeviceToDevice, s);
         if (rc != hipSuccess) return rc;
     }
-    UpArgs a{};
-    a.src = src; a.dst = dst; a.src_frame_stride = src_frame_stride;
-    a.frame_stride = g.frame_stride; a.plane_stride = g.plane_stride; a.row_pitch = g.row_pitch;
-    a.w = g.width; a.h = g.height; a.cw = (g.width + 1) >> 1; a.ch = (g.height + 1) >> 1; a.depth = g.depth;
-    a.htaps = u->htaps; a.vtaps = u->vtaps; a.hf = u->d_hf; a.vf = u->d_vf; a.hp = u->d_hp; a.vp = u->d_vp;
-    const dim3 grid((unsigned)((g.width + 255) / 256), (unsigned)g.height, (unsigned)(2 * nframes)), block(256);
-    if (bps == 1) hipLaunchKernelGGL(ffv2_upconv_kernel<1>, grid, block, 0, s, a);
-    else          hipLaunchKernelGGL(ffv2_upconv_kernel<2>, grid, block, 0, s, a);
-    return hipGetLastError();
+    const size_t cw = (size_t)((g.width + 1) >> 1), ch = (size_t)((g.height + 1) >> 1);
+    return ffv2_launch_upconv_chroma(u, g, nframes, src + (size_t)g.width * g.height * bps, cw * bps, cw * ch * bps,
+                                     src_frame_stride, dst, s);
 }

@@ -13,11 +13,15 @@
 #include <string.h>
 
 typedef struct FFV2AMDEncCtx {      /* the role of FFV2EncCtx, ffv2enc.c:29-53 */
-    ffv2amd_encoder *enc;
+    ffv2amd_encoder *enc;           /* == encs[0]: encode2's device */
+    ffv2amd_encoder *encs[FFV2AMD_MAX_DEVICES];   /* one per entry of the device list (frame fan-out) */
+    int ndev;
     ffv2amd_info info;
     uint8_t *scratch;
     size_t scratch_cap;
     int ring_open;
+    int mode;                       /* frames in flight came in through: 0 nothing yet, 1 the ring (qp 0), 2 the qp > 0 pipeline */
+    uint64_t sent, received;        /* frame n lives on device n % ndev */
     int verbose;                    /* FFV2AMD_VERBOSE: the reference's per-frame size line */
 } FFV2AMDEncCtx;
 
@@ -49,7 +53,8 @@ int ffv2amd_codec_close(FFV2AMDCodecContext *avctx)
     if (!avctx || !avctx->priv_data)
         return 0;
     s = avctx->priv_data;
-    ffv2amd_encoder_destroy(s->enc);
+    for (int d = 0; d < FFV2AMD_MAX_DEVICES; d++)
+        ffv2amd_encoder_destroy(s->encs[d]);
     free(s->scratch);
     free(s);
     avctx->priv_data = NULL;
@@ -70,10 +75,18 @@ int ffv2amd_codec_init(FFV2AMDCodecContext *avctx)
     if (!s)
         return FFV2AMD_ERR_NOMEM;
     avctx->priv_data = s;
-    ret = ffv2amd_encoder_create(&s->enc, avctx->width, avctx->height, avctx->pix_fmt,
-                                 avctx->hip_device, 1);
-    if (ret < 0)
+    s->ndev = avctx->nb_devices > 1 ? avctx->nb_devices : 1;
+    if (s->ndev > FFV2AMD_MAX_DEVICES) {
+        ret = FFV2AMD_ERR_INVAL;
         goto fail;
+    }
+    for (int d = 0; d < s->ndev; d++) {
+        ret = ffv2amd_encoder_create(&s->encs[d], avctx->width, avctx->height, avctx->pix_fmt,
+                                     avctx->nb_devices > 1 ? avctx->hip_devices[d] : avctx->hip_device, 1);
+        if (ret < 0)
+            goto fail;
+    }
+    s->enc = s->encs[0];
     if ((ret = ffv2amd_encoder_info(s->enc, &s->info)) < 0)
         goto fail;
     /* qp = global_quality > 0 packets are larger than the qp == 0 bound (ffv2amd_info) */
@@ -88,6 +101,19 @@ int ffv2amd_codec_init(FFV2AMDCodecContext *avctx)
 fail:
     ffv2amd_codec_close(avctx);
     return ret;
+}
+
+static int grow_scratch(FFV2AMDEncCtx *s, size_t want)
+{
+    uint8_t *g;
+    if (s->scratch_cap >= want)
+        return 0;
+    g = realloc(s->scratch, want);
+    if (!g)
+        return FFV2AMD_ERR_NOMEM;
+    s->scratch = g;
+    s->scratch_cap = want;
+    return 0;
 }
 
 /* the encoder owns the payload and hands it over (daala_entropy.c:727-732) */
@@ -114,14 +140,9 @@ int ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
         return FFV2AMD_ERR_INVAL;
     s = avctx->priv_data;
     *got_packet_ptr = 0;
-    if (avctx->global_quality > 0 && s->scratch_cap < s->info.packet_cap_qp) {
-        /* global_quality was raised after init: grow to the bound for any qp */
-        uint8_t *g = realloc(s->scratch, s->info.packet_cap_qp);
-        if (!g)
-            return FFV2AMD_ERR_NOMEM;
-        s->scratch = g;
-        s->scratch_cap = s->info.packet_cap_qp;
-    }
+    /* global_quality raised after init: grow to the bound for any qp */
+    if (avctx->global_quality > 0 && (ret = grow_scratch(s, s->info.packet_cap_qp)) < 0)
+        return ret;
     ret = ffv2amd_encode_frame(s->enc, frame->data, frame->linesize, avctx->global_quality,
                                NULL, s->scratch, s->scratch_cap, &n);
     if (ret < 0)
@@ -161,38 +182,70 @@ int ffv2amd_codec_encode_yuv420(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt
     return 0;
 }
 
-/* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449) over the asynchronous ring:
- * up to avctx->ring_depth frames in flight, packets in send order, pts carried as the tag.
- * qp == 0 only (FFV2AMD_ERR_UNSUPPORTED otherwise). */
+/* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449): the caller is ONE thread feeding
+ * frames and collecting packets; frames are independent (ffv2enc.c:461-469), so frame n goes to
+ * device n % ndev -- each device has its own encoder and asynchronous ring (global_quality 0) or
+ * two-deep qp > 0 pipeline -- and packets are handed back in send order with the frame's pts. */
 int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *frame, unsigned flags)
 {
     FFV2AMDEncCtx *s;
+    ffv2amd_encoder *enc;
+    const int qp = avctx ? avctx->global_quality : 0;
     int ret;
-    if (!avctx || !avctx->priv_data || !frame)
+    if (!avctx || !avctx->priv_data || !frame || qp < 0)
         return FFV2AMD_ERR_INVAL;
-    if (avctx->global_quality != 0)
-        return FFV2AMD_ERR_UNSUPPORTED;
     s = avctx->priv_data;
-    if (!s->ring_open) {
-        if ((ret = ffv2amd_ring_open(s->enc, avctx->ring_depth > 0 ? avctx->ring_depth : 4)) < 0)
-            return ret;
-        s->ring_open = 1;
+    if (s->sent != s->received && s->mode != (qp > 0 ? 2 : 1))
+        return FFV2AMD_ERR_INVAL;               /* global_quality changed with frames in flight */
+    enc = s->encs[s->sent % (uint64_t)s->ndev];
+    if (qp > 0) {
+        if (flags & FFV2AMD_FRAME_YUV420)
+            return FFV2AMD_ERR_UNSUPPORTED;
+        ret = ffv2amd_qp_send_frame(enc, frame->data, frame->linesize, qp, NULL, frame->pts);
+    } else {
+        if (!s->ring_open) {
+            for (int d = 0; d < s->ndev; d++)
+                if ((ret = ffv2amd_ring_open(s->encs[d], avctx->ring_depth > 0 ? avctx->ring_depth : 4)) < 0) {
+                    while (d-- > 0)
+                        ffv2amd_ring_close(s->encs[d]);
+                    return ret;
+                }
+            s->ring_open = 1;
+        }
+        ret = flags & FFV2AMD_FRAME_YUV420
+            ? ffv2amd_ring_send_420(enc, frame->data, frame->linesize, NULL, frame->pts, flags & FFV2AMD_FRAME_PINNED)
+            : ffv2amd_ring_send(enc, frame->data, frame->linesize, NULL, frame->pts, flags & FFV2AMD_FRAME_PINNED);
     }
-    return ffv2amd_ring_send(s->enc, frame->data, frame->linesize, NULL, frame->pts, flags);
+    if (ret < 0)
+        return ret;
+    s->mode = qp > 0 ? 2 : 1;
+    s->sent++;
+    return 0;
 }
 
 int ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt, int wait)
 {
     FFV2AMDEncCtx *s;
+    ffv2amd_encoder *enc;
     size_t n = 0;
     int64_t pts = 0;
     int ret;
     if (!avctx || !avctx->priv_data || !avpkt)
         return FFV2AMD_ERR_INVAL;
     s = avctx->priv_data;
-    if (!s->ring_open)
+    if (s->received == s->sent)
         return FFV2AMD_ERR_AGAIN;
-    ret = ffv2amd_ring_receive(s->enc, s->scratch, s->scratch_cap, &n, &pts, wait);
+    enc = s->encs[s->received % (uint64_t)s->ndev];
+    if (s->mode == 2) {
+        if ((ret = grow_scratch(s, s->info.packet_cap_qp)) < 0)
+            return ret;
+        ret = ffv2amd_qp_receive_packet(enc, s->scratch, s->scratch_cap, &n, &pts);
+    } else {
+        ret = ffv2amd_ring_receive(enc, s->scratch, s->scratch_cap, &n, &pts, wait);
+    }
+    if (ret == FFV2AMD_ERR_AGAIN || ret == FFV2AMD_ERR_INVAL)
+        return ret;
+    s->received++;                              /* delivered or failed, the oldest frame has left */
     if (ret < 0)
         return ret;
     return hand_over(s, avpkt, n, pts);

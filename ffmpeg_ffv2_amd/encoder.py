@@ -393,6 +393,43 @@ class FFV2Encoder:
         _lib.check(r, "ring_send")
         return True
 
+    def ring_send_420(self, y, u, v, tag=0, pinned=False):
+        """A yuv420p* frame through the ring (Y (H,W); U, V (ceil(H/2), ceil(W/2)), any row stride): half the
+        PCIe bytes of its 4:4:4 form, up-converted on the frame's compute stream.  False when the ring is full."""
+        i = self.info
+        cw, ch = (i.width + 1) // 2, (i.height + 1) // 2
+        for a, shp in ((y, (i.height, i.width)), (u, (ch, cw)), (v, (ch, cw))):
+            assert a.dtype == self.dtype and a.shape == shp and a.strides[1] == self.dtype.itemsize, (a.dtype, a.shape)
+        data = (C.c_void_p * 3)(y.ctypes.data, u.ctypes.data, v.ctypes.data)
+        ls = (C.c_ssize_t * 3)(y.strides[0], u.strides[0], v.strides[0])
+        r = self._lib.ffv2amd_ring_send_420(self._h, data, ls, None, int(tag), 1 if pinned else 0)
+        if r == -11:
+            return False
+        _lib.check(r, "ring_send_420")
+        return True
+
+    def pinned_frames_420(self, count):
+        """count page-locked yuv420p* frames as a list of (Y, U, V) sample arrays whose row strides equal the
+        device pitches (one DMA per plane), for ring_send_420(pinned=True).  Free with free_pinned()."""
+        i = self.info
+        bps = self.dtype.itemsize
+        cw, ch = (i.width + 1) // 2, (i.height + 1) // 2
+        cp = (cw * bps + 127) // 128 * 128
+        per = i.row_pitch * i.height + 2 * cp * ch
+        ptr = self._lib.ffv2amd_host_alloc(count * per)
+        if not ptr:
+            raise MemoryError("ffv2amd_host_alloc(%d)" % (count * per))
+        self._pinned = getattr(self, "_pinned", []) + [ptr]
+        buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(count * per,))
+        out = []
+        for n in range(count):
+            b = buf[n * per: (n + 1) * per]
+            yy = b[: i.row_pitch * i.height].reshape(i.height, i.row_pitch).view(self.dtype)[:, : i.width]
+            uu = b[i.row_pitch * i.height:][: cp * ch].reshape(ch, cp).view(self.dtype)[:, : cw]
+            vv = b[i.row_pitch * i.height + cp * ch:][: cp * ch].reshape(ch, cp).view(self.dtype)[:, : cw]
+            out.append((yy, uu, vv))
+        return out
+
     def ring_receive(self, wait=True):
         """-> (tag, packet bytes) of the oldest frame in flight, or None (nothing in flight /
         wait=False and not finished yet).  A failed frame raises FFV2Error."""
@@ -437,6 +474,13 @@ class FFV2Encoder:
         t, x, n = C.c_double(0), C.c_double(0), C.c_int(0)
         _lib.check(self._lib.ffv2amd_profile_read(self._h, C.byref(t), C.byref(x), C.byref(n)), "profile_read")
         return t.value, x.value, n.value
+
+    def profile_read_ex(self):
+        """-> (tstage_ms_total, estage_ms_total, launches, shortest T-stage launch ms, longest) since the last read."""
+        t, x, n, lo, hi = C.c_double(0), C.c_double(0), C.c_int(0), C.c_double(0), C.c_double(0)
+        _lib.check(self._lib.ffv2amd_profile_read_ex(self._h, C.byref(t), C.byref(x), C.byref(n), C.byref(lo), C.byref(hi)),
+                   "profile_read_ex")
+        return t.value, x.value, n.value, lo.value, hi.value
 
     @staticmethod
     def collect(pk, sizes, status):

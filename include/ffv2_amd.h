@@ -158,6 +158,15 @@ int  ffv2amd_encoder_set_device_coder(ffv2amd_encoder *enc, int on);
 int  ffv2amd_qp_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                        uint32_t *h_sizes, int32_t *h_status);
+/* == avcodec_send_frame / avcodec_receive_packet (encode.c:420,449) for global_quality 1..64: host
+ * frames through that pipeline, one frame per batch, at most two in flight (FFV2AMD_ERR_AGAIN).
+ * receive runs the oldest frame's range coder on the calling thread while the GPU works on the
+ * frame sent after it; a frame the reference would abort on returns FFV2AMD_ERR_ABORT and leaves
+ * the pipeline.  Do not mix with ffv2amd_qp_submit on one encoder.  Parity unpinned (qp > 0). */
+int  ffv2amd_qp_send_frame(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                           int qp, const int32_t *W, int64_t tag);
+int  ffv2amd_qp_receive_packet(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag);
+int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
 
 /* qp > 0 with MANY FRAMES IN FLIGHT (ffv2_lanecoder.hip).  The range coder
  * is one dependent chain per frame (ffv2enc.c:461,466), so the device codes many frames side by
@@ -248,11 +257,19 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
  *                  Copies back the packet's own size, not the capacity.  A frame that fails
  *                  (status < 0) is dropped from the ring and its error returned. */
 #define FFV2AMD_FRAME_PINNED 1u
+#define FFV2AMD_FRAME_YUV420 2u      /* ffv2amd_codec_send_frame only: a 4:2:0 frame (== ffv2amd_ring_send_420) */
 int   ffv2amd_ring_open(ffv2amd_encoder *enc, int depth);
 int   ffv2amd_ring_send(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
                         const int32_t *W, int64_t tag, unsigned flags);
 int   ffv2amd_ring_receive(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size,
                            int64_t *tag, int wait);
+/* The same for yuv420p / yuv420p10le / yuv420p12le frames (encoder created with the yuv444p* format of
+ * the same depth; data[0..2] = Y, U, V with their own linesizes): what the ffmpeg tool's auto-inserted
+ * bicubic scale filter does in front of encode2 (see ffv2amd_encode_frame_420), on the frame's compute
+ * stream.  Half the bytes cross PCIe; luma is copied straight into plane 0.  May be mixed with
+ * ring_send on one ring.  Parity unpinned. */
+int   ffv2amd_ring_send_420(ffv2amd_encoder *enc, const uint8_t *const data[3], const ptrdiff_t linesize[3],
+                            const int32_t *W, int64_t tag, unsigned flags);
 int   ffv2amd_ring_pending(const ffv2amd_encoder *enc);
 void  ffv2amd_ring_close(ffv2amd_encoder *enc);
 /* page-locked host memory for frame pools feeding ring_send(FFV2AMD_FRAME_PINNED) */
@@ -272,6 +289,9 @@ const char *ffv2amd_tstage_kernel_name(ffv2amd_encoder *enc, int nframes);
  * -1 = automatic (the default; the environment variable FFV2AMD_TSTAGE sets the same at start-up). */
 void ffv2amd_debug_force_tstage(int mode);
 int  ffv2amd_profile_read(ffv2amd_encoder *enc, double *tstage_ms, double *estage_ms, int *launches);
+/* The same, plus the shortest and the longest single T-stage launch among them (ms). */
+int  ffv2amd_profile_read_ex(ffv2amd_encoder *enc, double *tstage_ms, double *estage_ms, int *launches,
+                             double *tstage_min_ms, double *tstage_max_ms);
 
 /* Host helpers with no GPU work (unit-tested on CPU):
  * coded band gain for an integer band energy, bit-identical to

@@ -24,13 +24,21 @@
 extern "C" {
 #endif
 
+#define FFV2AMD_MAX_DEVICES 16
+
 typedef struct FFV2AMDCodecContext {
     int width, height;
     int pix_fmt;            /* enum AVPixelFormat value                       */
     int global_quality;     /* qp (ffv2enc.c:460); default 0                  */
     int hip_device;         /* extension: HIP ordinal, default 0              */
-    int ring_depth;         /* extension: frames in flight for send_frame/receive_packet, default 4 */
+    int ring_depth;         /* extension: frames in flight PER DEVICE for send_frame/receive_packet, default 4 */
     void *priv_data;        /* owned by init/close                            */
+    /* extension: frame-level fan-out over several GPUs behind ONE context (frames are independent,
+     * ffv2enc.c:461-469).  nb_devices > 1: send_frame deals frame n to hip_devices[n % nb_devices]
+     * (one encoder + ring per entry; an ordinal may appear more than once), receive_packet delivers
+     * in send order.  nb_devices <= 1: hip_device alone.  encode2 always runs on the first device. */
+    int nb_devices;
+    int hip_devices[FFV2AMD_MAX_DEVICES];
 } FFV2AMDCodecContext;
 
 typedef struct FFV2AMDFrame {
@@ -60,8 +68,15 @@ int  ffv2amd_codec_encode2(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt,
                            const FFV2AMDFrame *frame, int *got_packet_ptr);  /* :453 */
 int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:515     */
 /* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449): asynchronous, up to ring_depth
- * frames in flight, FFV2AMD_ERR_AGAIN (= AVERROR(EAGAIN)) when full / nothing ready; packets in
- * send order with the frame's pts.  flags: FFV2AMD_FRAME_PINNED of ffv2_amd.h.  qp == 0 only. */
+ * frames in flight per device, FFV2AMD_ERR_AGAIN (= AVERROR(EAGAIN)) when full (receive a packet,
+ * then send again) / nothing ready; packets in send order with the frame's pts, whichever device
+ * finishes first.  flags: FFV2AMD_FRAME_PINNED, FFV2AMD_FRAME_YUV420 of ffv2_amd.h (the latter:
+ * frame->data[0..2] = Y, U, V of a yuv420p* frame of the context's depth, see
+ * ffv2amd_codec_encode_yuv420; global_quality 0 only).
+ * global_quality 1..64 goes through ffv2amd_qp_send_frame / _receive_packet: two frames in flight per
+ * device, receive_packet always waits (it runs the frame's range coder), a frame the reference
+ * would abort on comes back as FFV2AMD_ERR_ABORT.  global_quality must not change while frames
+ * are in flight.  A frame that fails leaves the pipeline: the next receive is the next frame. */
 int  ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *frame, unsigned flags);
 int  ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpkt, int wait);
 /* The ffmpeg tool's format step + encode2 for yuv420p / yuv420p10le / yuv420p12le sources

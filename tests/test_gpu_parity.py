@@ -413,17 +413,7 @@ def test_raw_frame_cli_reproduces_reference_md5(tmp_path):
 def test_avcodec_shaped_shim(oracle):
     """init / encode2 / close of ffv2enc_amd.c (the AVCodec surface)."""
     from ffmpeg_ffv2_amd import _lib
-
-    class Ctx(C.Structure):
-        _fields_ = [("width", C.c_int), ("height", C.c_int), ("pix_fmt", C.c_int),
-                    ("global_quality", C.c_int), ("hip_device", C.c_int), ("ring_depth", C.c_int),
-                    ("priv_data", C.c_void_p)]
-
-    class Frame(C.Structure):
-        _fields_ = [("data", C.c_void_p * 4), ("linesize", C.c_ssize_t * 4), ("pts", C.c_int64)]
-
-    class Packet(C.Structure):
-        _fields_ = [("data", C.POINTER(C.c_uint8)), ("size", C.c_int), ("pts", C.c_int64), ("dts", C.c_int64)]
+    from tests.codec_ctypes import Ctx, Frame, Packet
 
     lib = _lib.load()
     ctx = Ctx(320, 240, 5, 0, 0, 0, None)

@@ -154,3 +154,103 @@ def test_device_range_coder_abort_conditions(oracle):
         enc.encode_batch_to_host(enc.upload(flat), qp=16)
     assert host_code == ei2.value.code == -1
     enc.close()
+
+
+# ---- 4:2:0 frames through the ring (SURVEY.md 8(f) rank 4 at the asynchronous boundary) ----
+def _yuv420(seed, h, w, depth, kind="noise"):
+    rng = np.random.default_rng(seed)
+    dt = np.uint8 if depth == 8 else np.dtype("<u2")
+    ch, cw = (h + 1) // 2, (w + 1) // 2
+    if kind == "noise":
+        return [rng.integers(0, 1 << depth, s).astype(dt) for s in ((h, w), (ch, cw), (ch, cw))]
+    yy, xx = np.mgrid[0:ch, 0:cw]
+    ramp = ((3 * xx + 5 * yy + seed) % (1 << depth)).astype(dt)
+    y2, x2 = np.mgrid[0:h, 0:w]
+    return [((7 * x2 + 3 * y2 + (x2 * y2 >> 6) + seed) % (1 << depth)).astype(dt), ramp, ramp[::-1].copy()]
+
+
+FMT444 = {8: "yuv444p", 10: "yuv444p10le", 12: "yuv444p12le"}
+
+
+@pytest.mark.parametrize("depth,h,w", [(8, 240, 320), (10, 130, 200), (12, 65, 129), (8, 37, 51), (10, 1080, 1920)])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_ring_420_matches_convert_then_encode(oracle, depth, h, w, pinned):
+    """yuv420p* frames through ffv2amd_ring_send_420: packets == oracle.encode(oracle.sws_420_to_444(frame)),
+    delivered in send order, interleaved with 4:4:4 frames on the same ring.  Parity unpinned (swscale)."""
+    fmt = FMT444[depth]
+    enc = _enc(w, h, fmt)
+    enc.ring_open(3)
+    src = [_yuv420(20 + n, h, w, depth, "noise" if n % 2 else "ramp") for n in range(5)]
+    conv = [oracle.sws_420_to_444(y, u, v, depth) for y, u, v in src]
+    want = [oracle.encode(c, fmt) for c in conv]
+    if pinned:
+        pool = enc.pinned_frames_420(len(src))
+        for (py, pu, pv), (y, u, v) in zip(pool, src):
+            py[:] = y; pu[:] = u; pv[:] = v
+        send = pool
+    else:
+        send = src
+    order = [0, 1, 2, 99, 3, 4]              # 99: a 4:4:4 frame in between, on the same ring
+    got, sent = [], 0
+    while len(got) < len(order):
+        while sent < len(order):
+            t = order[sent]
+            ok = enc.ring_send(conv[0], tag=99) if t == 99 else enc.ring_send_420(*send[t], tag=t, pinned=pinned)
+            if not ok:
+                break
+            sent += 1
+        got.append(enc.ring_receive(wait=True))
+    tags = [t for t, _ in got]
+    assert tags == [0, 1, 2, 99, 3, 4]
+    for t, pk in got:
+        assert pk == want[0 if t == 99 else t], "packet %d differs from convert-then-encode" % t
+    enc.ring_close()
+    enc.free_pinned()
+    enc.close()
+
+
+@pytest.mark.parametrize("depth,h,w", [(10, 2160, 3840), (12, 4320, 7680)])
+def test_ring_420_literal_baseline_formats_full_size(oracle, depth, h, w):
+    """BASELINE configs 3 and 5 as they are written (3840x2160 yuv420p10le, 7680x4320 yuv420p12le), host
+    frame in, packet out; the up-converted picture is also held sample by sample to the oracle's."""
+    fmt = FMT444[depth]
+    enc = _enc(w, h, fmt)
+    y, u, v = _yuv420(3, h, w, depth, "ramp")
+    rng = np.random.default_rng(5)
+    u[: h // 4] = rng.integers(0, 1 << depth, u[: h // 4].shape)       # noise and structure in one frame
+    want444 = oracle.sws_420_to_444(y, u, v, depth)
+    got444 = enc.upconvert_420(y, u, v)
+    bad = np.argwhere(got444 != want444)
+    assert len(bad) == 0, "first mismatch at (plane, y, x) = %s" % (bad[0],)
+    enc.ring_open(2)
+    assert enc.ring_send_420(y, u, v, tag=7)
+    tag, pk = enc.ring_receive()
+    assert tag == 7 and pk == oracle.encode(want444, fmt)
+    enc.ring_close()
+    enc.close()
+
+
+def test_upconv_tiled_and_per_sample_kernels_agree(oracle, monkeypatch):
+    """Odd geometries through both up-conversion kernels (FFV2AMD_UPCONV_NAIVE is read once per process, so
+    the per-sample kernel is reached through a subprocess)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\\n"
+        "sys.path.insert(0, %r)\\n"
+        "from ffmpeg_ffv2_amd import FFV2Encoder\\n"
+        "from tests import oracle_lib\\n"
+        "o = oracle_lib.load()\\n"
+        "for depth, h, w in ((8, 67, 131), (10, 33, 257), (12, 200, 130), (8, 9, 300), (10, 17, 16)):\\n"
+        "    rng = np.random.default_rng(h * w)\\n"
+        "    dt = np.uint8 if depth == 8 else np.dtype('<u2')\\n"
+        "    y, u, v = [rng.integers(0, 1 << depth, s).astype(dt) for s in ((h, w), ((h + 1) // 2, (w + 1) // 2), ((h + 1) // 2, (w + 1) // 2))]\\n"
+        "    e = FFV2Encoder(w, h, {8: 'yuv444p', 10: 'yuv444p10le', 12: 'yuv444p12le'}[depth])\\n"
+        "    assert (e.upconvert_420(y, u, v) == o.sws_420_to_444(y, u, v, depth)).all(), (depth, h, w)\\n"
+        "    e.close()\\n"
+        "print('ok')\\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for naive in ("0", "1"):
+        env = dict(os.environ, FFV2AMD_UPCONV_NAIVE=naive)
+        r = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True)
+        assert r.returncode == 0 and "ok" in r.stdout, (naive, r.stdout, r.stderr)

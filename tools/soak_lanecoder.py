@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """GPU box: random sizes / formats / qp / content through the many-frames-in-flight coder
 (ffv2amd_lanecoder_*) against the host coder (ffv2amd_encode_batch_to_host), frame by frame.
-usage: python tools/soak_lanecoder.py [cases=300] [seed=1]"""
+Frames of very different lengths share a group of lanes on purpose ("quiet", "half"): the chain
+kernel's LDS ring between its two wavefronts is ordered by hand (ffv2_lanecoder.hip), uneven
+progress of the lanes is what would expose a mistake there.
+usage: python tools/soak_lanecoder.py [cases=300] [seed=1]
+tests/test_soak_gpu.py runs a fixed-seed slice of it in the -m gpu suite."""
 import os
 import random
 import sys
@@ -10,51 +14,61 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth  # noqa: E402
-from ffmpeg_ffv2_amd._lib import FFV2Error  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-fmts = [("gray", 1, 8), ("yuv444p", 3, 8), ("yuv444p10le", 3, 10), ("gbrp12le", 3, 12), ("yuv444p12le", 3, 12), ("gbrp", 3, 8)]
-checked = aborted = symbols = 0
-t0 = time.time()
-for it in range(cases):
-    fmt, P, depth = rnd.choice(fmts)
-    W, H = rnd.randint(1, 400), rnd.randint(1, 300)
-    qp = rnd.randint(2, 64)
-    n = rnd.randint(1, 9)
-    enc = FFV2Encoder(W, H, fmt, device=0, max_batch=rnd.randint(1, 4))
-    frames = []
-    for i in range(n):
-        k = rnd.choice(["S2", "S2", "S1", "quiet", "half"])
-        if k == "quiet":
-            f = synth.noise(it * 16 + i, P, H, W, depth)
-            f = (f % rnd.choice([2, 5, 16]) + (1 << (depth - 1))).astype(f.dtype)
-        elif k == "half":
-            f = synth.noise(it * 16 + i, P, H, W, depth)
-            f[:, H // 2:, :] = 1 << (depth - 1)
-        else:
-            f = synth.make(k, it * 16 + i, P, H, W, depth)
-        frames.append(f)
-    frames = np.stack(frames)
-    dev = enc.upload(frames)
-    enc.lanecoder_open(n, rnd.choice([0, 0, 4096 + enc.info.block_planes * 600]))
-    pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
-    for i in range(n):
-        try:
-            want = enc.encode_batch_to_host(dev[i:i + 1], qp=qp)[0]
-        except FFV2Error as e:
-            assert status[i] == e.code, (it, i, status[i], e.code)
-            aborted += 1
-            continue
-        if status[i] == -28:                      # tight packet_cap: allowed, must really not fit
-            assert len(want) > 4096 + enc.info.block_planes * 600 - 64, (it, i, len(want))
-            continue
-        assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == want, (it, i, fmt, W, H, qp)
-        checked += 1
-        symbols += len(want)
-    enc.close()
-    if it % 25 == 24:
-        print("%d cases, %d frames identical, %d aborts agreed, %.0f s" % (it + 1, checked, aborted, time.time() - t0), flush=True)
-print("soak_lanecoder: %d cases, %d frames identical (%.1f MB of packets), %d aborts agreed" % (cases, checked, symbols / 1e6, aborted))
+FMTS = [("gray", 1, 8), ("yuv444p", 3, 8), ("yuv444p10le", 3, 10), ("gbrp12le", 3, 12), ("yuv444p12le", 3, 12), ("gbrp", 3, 8)]
+
+
+def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False):
+    """Returns (frames identical, aborts agreed, packet bytes compared)."""
+    from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth
+    from ffmpeg_ffv2_amd._lib import FFV2Error
+    rnd = random.Random(seed)
+    checked = aborted = nbytes = 0
+    t0 = time.time()
+    for it in range(cases):
+        fmt, P, depth = rnd.choice(FMTS)
+        W, H = rnd.randint(1, max_w), rnd.randint(1, max_h)
+        qp = rnd.randint(2, 64)
+        n = rnd.randint(1, max_frames)
+        enc = FFV2Encoder(W, H, fmt, device=0, max_batch=rnd.randint(1, 4))
+        frames = []
+        for i in range(n):
+            k = rnd.choice(["S2", "S2", "S1", "quiet", "half"])
+            if k == "quiet":
+                f = synth.noise(it * 16 + i, P, H, W, depth)
+                f = (f % rnd.choice([2, 5, 16]) + (1 << (depth - 1))).astype(f.dtype)
+            elif k == "half":
+                f = synth.noise(it * 16 + i, P, H, W, depth)
+                f[:, H // 2:, :] = 1 << (depth - 1)
+            else:
+                f = synth.make(k, it * 16 + i, P, H, W, depth)
+            frames.append(f)
+        frames = np.stack(frames)
+        dev = enc.upload(frames)
+        enc.lanecoder_open(n, rnd.choice([0, 0, 4096 + enc.info.block_planes * 600]))
+        pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+        for i in range(n):
+            try:
+                want = enc.encode_batch_to_host(dev[i:i + 1], qp=qp)[0]
+            except FFV2Error as e:
+                assert status[i] == e.code, (it, i, status[i], e.code)
+                aborted += 1
+                continue
+            if status[i] == -28:                      # tight packet_cap: allowed, must really not fit
+                assert len(want) > 4096 + enc.info.block_planes * 600 - 64, (it, i, len(want))
+                continue
+            assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == want, (it, i, fmt, W, H, qp)
+            checked += 1
+            nbytes += len(want)
+        enc.close()
+        if it % 25 == 24 and not quiet:
+            print("%d cases, %d frames identical, %d aborts agreed, %.0f s" % (it + 1, checked, aborted, time.time() - t0), flush=True)
+    return checked, aborted, nbytes
+
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    checked, aborted, nbytes = run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("soak_lanecoder: %d cases, %d frames identical (%.1f MB of packets), %d aborts agreed" % (cases, checked, nbytes / 1e6, aborted))

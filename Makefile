@@ -5,7 +5,7 @@ CC      ?= gcc
 HIPFLAGS = --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-strict-aliasing -ffp-contract=off -Wall
 CSRC     = ffmpeg_ffv2_amd/csrc
 LIB      = ffmpeg_ffv2_amd/libffv2amd.so
-OBJS     = $(CSRC)/ffv2_kernels.o $(CSRC)/ffv2_pvq.o $(CSRC)/ffv2_inverse.o $(CSRC)/ffv2_upconv.o $(CSRC)/ffv2_rangecoder.o $(CSRC)/ffv2_lanecoder.o $(CSRC)/ffv2_capi.o $(CSRC)/ffv2enc_amd.o $(CSRC)/ffv2mkv.o
+OBJS     = $(CSRC)/ffv2_kernels.o $(CSRC)/ffv2_pvq.o $(CSRC)/ffv2_inverse.o $(CSRC)/ffv2_upconv.o $(CSRC)/ffv2_wide.o $(CSRC)/ffv2_rangecoder.o $(CSRC)/ffv2_lanecoder.o $(CSRC)/ffv2_capi.o $(CSRC)/ffv2enc_amd.o $(CSRC)/ffv2mkv.o
 
 all: $(LIB) examples/ffv2enc_cli oracle
 

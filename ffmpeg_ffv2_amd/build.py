@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 SO = os.path.join(PKG, "libffv2amd.so")
 
-HIP_SOURCES = ["ffv2_kernels.hip", "ffv2_pvq.hip", "ffv2_inverse.hip", "ffv2_upconv.hip", "ffv2_rangecoder.hip", "ffv2_lanecoder.hip", "ffv2_capi.cpp"]
+HIP_SOURCES = ["ffv2_kernels.hip", "ffv2_pvq.hip", "ffv2_inverse.hip", "ffv2_upconv.hip", "ffv2_wide.hip", "ffv2_rangecoder.hip", "ffv2_lanecoder.hip", "ffv2_capi.cpp"]
 C_SOURCES = ["ffv2enc_amd.c", "ffv2mkv.c"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-strict-aliasing",
             "-ffp-contract=off", "-Wall"]

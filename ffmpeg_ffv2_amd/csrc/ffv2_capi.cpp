@@ -545,6 +545,9 @@ struct ffv2amd_encoder {
     uint8_t *qh_frame[2] = { nullptr, nullptr }, *qd_frame[2] = { nullptr, nullptr };
     int32_t *qd_w[2] = { nullptr, nullptr };
     int64_t q_tag[2] = { 0, 0 };
+    // wide (plain int32) T-stage of one frame: the rerun of frames the fast kernels refuse (ffv2_wide.hip)
+    int32_t *d_wide_plane = nullptr, *d_wide_c0 = nullptr;
+    int64_t *d_wide_en = nullptr;
     // 4:2:0 -> 4:4:4 front end (ffv2amd_*_420)
     FFV2Upconv *upconv = nullptr;
     bool upconv_tried = false;
@@ -556,6 +559,7 @@ struct ffv2amd_encoder {
         uint32_t *d_meta = nullptr, *h_meta = nullptr;      // [0] size, [1] status
         uint32_t *d_codes = nullptr, *d_bitcnt = nullptr;
         int32_t  *d_w = nullptr;
+        bool has_w = false;
         uint8_t  *d_c420 = nullptr;                         // U, V of a 4:2:0 frame, rows c_pitch apart (ring_send_420)
         hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_meta = nullptr;
         int64_t tag = 0;
@@ -704,6 +708,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     (void)hipFree(e->d_codes); (void)hipFree(e->d_bitoff); (void)hipFree(e->d_status); (void)hipFree(e->d_err);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
     (void)hipFree(e->d_inv_plane);
+    (void)hipFree(e->d_wide_plane); (void)hipFree(e->d_wide_c0); (void)hipFree(e->d_wide_en);
     (void)hipFree(e->d_coef_ws); (void)hipFree(e->d_y); (void)hipFree(e->d_pk_ws); (void)hipFree(e->d_sizes_ws);
     if (e->h_y) (void)hipHostFree(e->h_y);
     if (e->h_codes) (void)hipHostFree(e->h_codes);
@@ -757,9 +762,11 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     int r = range_prefix(pix_fmt, in.num_sb_x * in.num_sb_y, prefix, &e->slack);
     if (r < 0) { delete e; return r; }
     e->prefix_len = (int)prefix.size();
-    // worst case raw bits per block-plane: c0 (|c0| < 2^22: 43+1 bits) + 13 gains
-    // (<= 2^15: 31 bits each) + 4 tx bits per superblock  -> < 58 bytes
-    in.packet_cap = align_up((size_t)e->prefix_len + 16 + (size_t)in.block_planes * 58 + 64, 256);
+    // worst case raw bits per block-plane on the device path: c0 (|c0| < 2^22: 43+1 bits) + 13 gains
+    // (<= 2^15: 31 bits each) + 4 tx bits per superblock  -> < 58 bytes (what the E-stage's LDS holds);
+    // a frame with samples above its depth, coded on the host from the wide T-stage: c0 any int32
+    // (63+1 bits), gains < 2^22 (43 bits each) -> < 80 bytes
+    in.packet_cap = align_up((size_t)e->prefix_len + 16 + (size_t)in.block_planes * 80 + 64, 256);
     in.packet_cap_qp = in.packet_cap + (size_t)in.block_planes * 2100;   // generous; NOSPACE if ever exceeded
 
     FFV2Geom &g = e->geom;
@@ -1018,6 +1025,68 @@ int ffv2amd_encode_frame(ffv2amd_encoder *e,
     return encode_uploaded_frame(e, qp, W, out, out_cap, out_size);
 }
 
+// One frame through the wide T-stage (ffv2_wide.hip) and a host-assembled qp == 0 packet: what the
+// reference makes of a frame whose samples exceed the declared depth (ffv2.c:26-38 shifts whatever it
+// is given) or whose band gains leave the device's threshold table.  Synchronous, on the encoder's
+// stream; d_frame must be complete.  Gains with the host's own pow (ffv2enc.c:131-138,174).
+static int wide_tstage(ffv2amd_encoder *e, const uint8_t *d_frame, int32_t *d_coef, hipStream_t s)
+{
+    const FFV2Geom &g = e->geom;
+    if (!e->d_wide_plane) {
+        HIPCHK(hipMalloc(&e->d_wide_plane, sizeof(int32_t) * (size_t)g.nsx * 64 * g.nsy * 64 * g.planes));
+        HIPCHK(hipMalloc(&e->d_wide_c0, sizeof(int32_t) * g.nblk));
+        HIPCHK(hipMalloc(&e->d_wide_en, sizeof(int64_t) * 13 * g.nblk));
+    }
+    HIPCHK(ffv2_launch_wide_tstage(g, d_frame, e->d_wide_plane, d_coef, e->d_wide_en, e->d_wide_c0, s));
+    return FFV2AMD_OK;
+}
+
+static int wide_encode_frame(ffv2amd_encoder *e, const uint8_t *d_frame, const int32_t *d_W,
+                             uint8_t *out, size_t cap, size_t *size)
+{
+    const ffv2amd_info &in = e->info;
+    hipStream_t s = e->stream;
+    int r = wide_tstage(e, d_frame, nullptr, s);
+    if (r < 0) return r;
+    std::vector<int64_t> en;
+    std::vector<int32_t> c0, W;
+    try {
+        en.resize((size_t)13 * in.block_planes); c0.resize((size_t)in.block_planes);
+        if (d_W) W.resize((size_t)in.block_planes);
+    } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(en.data(), e->d_wide_en, sizeof(int64_t) * en.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c0.data(), e->d_wide_c0, sizeof(int32_t) * c0.size(), hipMemcpyDeviceToHost, s));
+    if (d_W) HIPCHK(hipMemcpyAsync(W.data(), d_W, sizeof(int32_t) * W.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    try {
+        PacketEnc pe;
+        const uint32_t hs = (uint32_t)in.pix_fmt >> 4;
+        auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
+        pe.rc.encode(hs ? q15(hs) : 0, q15(hs + 1), 32768);                 // ffv2enc.c:449
+        pe.bits((uint32_t)in.pix_fmt & 15u, 4);
+        pe.golomb(0);                                                       // qp
+        uint16_t subdiv[4] = { 32, 64, 96, 128 };
+        const int nsb = in.num_sb_x * in.num_sb_y;
+        for (int sb = 0; sb < nsb; sb++) {
+            pe.adapt(subdiv, 4, 128, 0);                                    // ffv2enc.c:222
+            pe.bits(0, 4);                                                  // :197
+            for (int p = 0; p < in.planes; p++) {
+                const size_t bp = (size_t)sb * in.planes + p;
+                const int32_t c = c0[bp];
+                pe.golomb(c < 0 ? (uint32_t)(-(int64_t)c) : (uint32_t)c);   // :148-150
+                if (c) pe.bits(c < 0, 1);
+                for (int b = 0; b < 13; b++) {
+                    int64_t eb = en[bp * 13 + b];
+                    if (b == 12 && d_W) eb = (int64_t)((uint64_t)eb + (uint64_t)((int64_t)W[bp] * W[bp]));   // phantom coefficient
+                    pe.golomb(coded_gain_host(eb));                         // :166,174
+                }
+            }
+        }
+        if (pe.abort_) return FFV2AMD_ERR_ABORT;
+        return pe.finish(out, cap, size);
+    } catch (...) { return FFV2AMD_ERR_NOMEM; }
+}
+
 // e->d_frame holds (or will hold, in order on e->stream) one 4:4:4 frame: encode it to `out`
 static int encode_uploaded_frame(ffv2amd_encoder *e, int qp, const int32_t *W, uint8_t *out, size_t out_cap, size_t *out_size)
 {
@@ -1046,6 +1115,8 @@ static int encode_uploaded_frame(ffv2amd_encoder *e, int qp, const int32_t *W, u
     HIPCHK(hipMemcpyAsync(e->h_pkt, e->d_pkt, in.packet_cap, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int32_t st = (int32_t)e->h_meta[1];
+    if (st == FFV2AMD_ERR_RANGE)       // samples above the declared depth / a gain beyond the table: the reference codes them
+        return wide_encode_frame(e, e->d_frame, dW, out, out_cap, out_size);
     if (st < 0) return st;
     const size_t n = e->h_meta[0];
     if (n == 0) return FFV2AMD_ERR_DEVICE;
@@ -1116,6 +1187,18 @@ int ffv2amd_encode_frame_420(ffv2amd_encoder *e, const uint8_t *const data[3], c
     HIPCHK(hipMemcpyAsync(e->d_420, e->h_420, total, hipMemcpyHostToDevice, s));
     HIPCHK(ffv2_launch_upconv(e->upconv, e->geom, 1, e->d_420, total, e->d_frame, s));
     return encode_uploaded_frame(e, qp, nullptr, out, out_cap, out_size);
+}
+
+int ffv2amd_tstage_wide_device(ffv2amd_encoder *e, const void *d_frame, int32_t *d_coef, int64_t *d_energy, void *stream)
+{
+    if (!e || !d_frame) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const int r = wide_tstage(e, (const uint8_t *)d_frame, d_coef, (hipStream_t)stream);
+    if (r < 0) return r;
+    if (d_energy)
+        HIPCHK(hipMemcpyAsync(d_energy, e->d_wide_en, sizeof(int64_t) * 13 * e->geom.nblk, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FFV2AMD_OK;
 }
 
 int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t *d_coef,
@@ -1693,6 +1776,15 @@ int ffv2amd_encode_batch_to_host(ffv2amd_encoder *e, int nframes, const void *d_
         HIPCHK(hipMemcpyAsync(tmp.data(), e->d_pk_ws, tmp.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         for (int f = 0; f < nframes; f++) {
+            if (h_status[f] == FFV2AMD_ERR_RANGE) {                  // the reference codes such a frame: rerun it wide
+                size_t n = 0;
+                const int rw = wide_encode_frame(e, (const uint8_t *)d_frames + (size_t)f * in.frame_stride,
+                                                 d_W ? d_W + (size_t)f * nb : nullptr, h_packets + (size_t)f * packet_stride,
+                                                 packet_stride, &n);
+                h_status[f] = rw;
+                h_sizes[f] = rw < 0 ? 0u : (uint32_t)n;
+                continue;
+            }
             if (h_status[f] < 0) continue;
             if (h_sizes[f] > packet_stride) { h_status[f] = FFV2AMD_ERR_NOSPACE; continue; }
             memcpy(h_packets + (size_t)f * packet_stride, tmp.data() + (size_t)f * in.packet_cap, h_sizes[f]);
@@ -1890,6 +1982,7 @@ static int ring_submit(ffv2amd_encoder *e, ffv2amd_encoder::RingSlot &r, const R
         for (int i = 0; i < nsl; i++) HIPCHK(up[i]);
     }
     const int32_t *dW = nullptr;
+    r.has_w = W != nullptr;
     if (W) {
         HIPCHK(hipMemcpyAsync(r.d_w, W, sizeof(int32_t) * in.block_planes, hipMemcpyHostToDevice, sh));
         dW = r.d_w;
@@ -1979,6 +2072,8 @@ int ffv2amd_ring_receive(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, size_
     e->ring_count--;
     if (tag) *tag = r.tag;
     const int32_t st = (int32_t)r.h_meta[1];
+    if (st == FFV2AMD_ERR_RANGE)       // the slot's device frame is intact until the next send: rerun it wide
+        return wide_encode_frame(e, r.d_frame, r.has_w ? r.d_w : nullptr, out, out_cap, out_size);
     if (st < 0) return st;
     const size_t n = r.h_meta[0];
     if (n == 0) return FFV2AMD_ERR_DEVICE;

@@ -137,3 +137,9 @@ struct FFV2LaneCoderArgs {
 hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
 hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s,                      // cdf, chain, finish of frames 0..nframes-1;
                                hipEvent_t chain_begin, hipEvent_t chain_end);                             // optional timing events around the chain kernel
+
+// The T-stage of ONE frame in plain wrapping int32 (ffv2_wide.hip): any 16-bit sample, any gain.
+// plane: int32 [planes][64 nsy][64 nsx] workspace; coef optional [nblk][4096]; energy [nblk][13]
+// (phantom W excluded); c0 [nblk].
+hipError_t ffv2_launch_wide_tstage(const FFV2Geom &g, const uint8_t *d_frame, int32_t *plane, int32_t *coef,
+                                   int64_t *energy, int32_t *c0, hipStream_t s);

@@ -105,6 +105,18 @@ class FFV2Encoder:
                                                    C.c_void_p(stream)), "ffv2amd_tstage_device")
         return coef, en
 
+    def tstage_wide(self, d_frame):
+        """One frame (torch uint8 (frame_stride,) or (1, frame_stride)) through the plain-int32 T-stage
+        (ffv2_wide.hip): any 16-bit sample.  -> (coef (block_planes, 4096) int32, energy (block_planes, 13) int64)."""
+        import torch
+        dev = d_frame.device
+        coef = torch.empty((self.info.block_planes, 4096), dtype=torch.int32, device=dev)
+        en = torch.empty((self.info.block_planes, 13), dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._lib.ffv2amd_tstage_wide_device(self._h, d_frame.data_ptr(), coef.data_ptr(), en.data_ptr(),
+                                                        C.c_void_p(stream)), "ffv2amd_tstage_wide_device")
+        return coef, en
+
     def alloc_packets(self, nframes):
         import torch
         dev = "cuda:%d" % self.device

@@ -28,8 +28,9 @@ extern "C" {
 #define FFV2AMD_ERR_NOMEM      (-12)  /* AVERROR(ENOMEM)                                        */
 #define FFV2AMD_ERR_DEVICE     (-5)   /* AVERROR(EIO): HIP runtime / device failure             */
 #define FFV2AMD_ERR_NOSPACE    (-28)  /* AVERROR(ENOSPC): caller's packet buffer too small      */
-#define FFV2AMD_ERR_RANGE      (-34)  /* AVERROR(ERANGE): a sample exceeds the declared depth,
-                                          or a band gain left the quantiser table                */
+#define FFV2AMD_ERR_RANGE      (-34)  /* AVERROR(ERANGE): a sample exceeds the declared depth, or a band
+                                          gain left the quantiser table, on a path that cannot rerun
+                                          the frame in int32 (see ffv2amd_tstage_wide_device)       */
 #define FFV2AMD_ERR_ABORT      (-1)   /* AVERROR(EPERM): the reference would av_assert0 -> abort
                                           (daala_entropy.c:336; qp > 0 only)                     */
 #define FFV2AMD_ERR_UNSUPPORTED (-38) /* AVERROR(ENOSYS)                                        */
@@ -112,6 +113,18 @@ int  ffv2amd_encode_batch_device(ffv2amd_encoder *enc, int nframes, const void *
  * Used by the parity tests and the roofline measurement. */
 int  ffv2amd_tstage_device(ffv2amd_encoder *enc, int nframes, const void *d_frames,
                            int32_t *d_coef, int64_t *d_energy, void *stream);
+
+/* The T-stage of ONE frame in plain wrapping int32 (ffv2_wide.hip), as the reference computes it for
+ * any 16-bit sample (ffv2.c:26-38 level-shifts whatever it is given).  The fast kernels stage samples
+ * as int16 and refuse a frame with samples above its declared depth, or a band gain beyond their
+ * 32 768-entry table, with FFV2AMD_ERR_RANGE in the frame's status; the entry points that end in host
+ * memory at qp == 0 (ffv2amd_encode_frame, _encode_frame_420, _encode_batch_to_host, _ring_receive,
+ * the codec shim) then rerun that frame through this path and assemble its packet on the host, so
+ * the caller gets the reference's packet, not an error.  ffv2amd_encode_batch_device (packets stay in
+ * HBM, no host in the loop) and every qp > 0 path report the status instead.  Outputs as
+ * ffv2amd_tstage_device; a test hook. */
+int  ffv2amd_tstage_wide_device(ffv2amd_encoder *enc, const void *d_frame, int32_t *d_coef, int64_t *d_energy,
+                                void *stream);
 
 /* Batch variant of encode2 that ends in host memory and accepts any qp >= 0
  * (synchronous).  Frames are resident in HBM (layout of ffv2amd_info); packets are

@@ -82,18 +82,18 @@ def test_device_list_equals_single_ring_byte_for_byte(oracle):
     assert outs[0] == outs[1]
 
 
-def test_a_failed_frame_leaves_and_the_order_holds(oracle):
+def test_a_frame_above_its_depth_keeps_its_place(oracle):
+    """ffv2.c:26-38 level-shifts any 16-bit sample: the frame is coded (through the wide path), in order."""
     lib = _lib()
     W, H = 192, 128
     frames = [synth.make("S1", n, 3, H, W, 10) for n in range(5)]
     frames[2] = frames[2].copy()
-    frames[2][0, 3, 3] = 1 << 10                              # above the declared depth -> ERANGE from that frame only
+    frames[2][0, 3, 3] = 1 << 10
     ctx = make_ctx(W, H, 70, ring_depth=2, devices=[0, 0])
     assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
     got = _drive(lib, ctx, frames)
-    assert got[2] == (None, -34)
-    for n in (0, 1, 3, 4):
-        assert got[n] == (500 + n, oracle.encode(frames[n], "yuv444p10le"))
+    for n in range(5):
+        assert got[n] == (500 + n, oracle.encode(frames[n], "yuv444p10le")), n
     assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0
 
 

@@ -77,19 +77,26 @@ def test_ring_later_frames_finish_while_the_oldest_is_held(oracle):
 
 
 def test_ring_reports_a_bad_frame_and_moves_on(oracle):
+    """A frame whose packet does not fit the caller's buffer fails alone (ENOSPC) and leaves the ring; a frame
+    with a sample above the declared depth is no failure: the reference codes it, receive reruns it wide."""
     W, H, fmt, P, depth = 192, 128, "yuv444p10le", 3, 10
     from ffmpeg_ffv2_amd._lib import FFV2Error
     enc = _enc(W, H, fmt)
-    enc.ring_open(2)
+    enc.ring_open(3)
     good = synth.make("S1", 0, P, H, W, depth)
-    bad = good.copy()
-    bad[1, 5, 7] = 1 << depth                     # above the declared depth
-    assert enc.ring_send(bad, tag=1) and enc.ring_send(good, tag=2)
+    odd = good.copy()
+    odd[1, 5, 7] = 1 << depth                     # above the declared depth
+    assert enc.ring_send(good, tag=1) and enc.ring_send(odd, tag=2) and enc.ring_send(good, tag=3)
+    full_out = enc._ring_out
+    enc._ring_out = np.empty(16, np.uint8)        # too small for the first packet
     with pytest.raises(FFV2Error) as ei:
         enc.ring_receive()
-    assert ei.value.code == -34
+    assert ei.value.code == -28
+    enc._ring_out = full_out
     tag, pk = enc.ring_receive()
-    assert tag == 2 and pk == oracle.encode(good, fmt)
+    assert tag == 2 and pk == oracle.encode(odd, fmt)
+    tag, pk = enc.ring_receive()
+    assert tag == 3 and pk == oracle.encode(good, fmt)
     enc.ring_close()
     enc.close()
 

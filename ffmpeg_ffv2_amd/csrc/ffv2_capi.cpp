@@ -450,6 +450,117 @@ struct GatherPool {
     }
 };
 
+// ------------------------------------------------------------------
+// Daala range DECODER, the subset an FFV2 packet needs (daala_entropy.c:79-105 fillup / renormalise,
+// :200-224 raw bits from the packet's end, :273-326 decode_cdf, :382-396 uint, :413-425 adaptive CDF,
+// :564-578 init) -- the entropy half of the decoder-side check (ffv2amd_decode_frame).
+// ------------------------------------------------------------------
+struct RangeDec {
+    const uint8_t *b;
+    size_t n, pos = 0, epos;
+    uint64_t diff = 0, win = 0;
+    uint32_t rng = 0x8000;
+    int cnt = -15, nwin = 0;
+    bool err = false;
+
+    RangeDec(const uint8_t *buf, size_t size) : b(buf), n(size), epos(size) { fill(); }
+    void fill()
+    {
+        int i = 64 - 9 - (cnt + 15);
+        for (; i >= 0 && pos < n; i -= 8, pos++) { diff |= (uint64_t)b[pos] << i; cnt += 8; }
+        if (pos >= n) cnt = 16384;                                   // DAALAENT_BIT_ABUNDANCE
+    }
+    void renorm(uint64_t d, uint32_t r)
+    {
+        const int i = 16 - RangeEnc::ilog(r);
+        diff = d << i; rng = r << i;
+        if ((cnt -= i) < 0) fill();
+    }
+    static uint32_t sat(uint32_t a, uint32_t c) { return a - (a < c ? a : c); }
+    int decode(const uint16_t *cdf, int nsym, bool q15)
+    {
+        const int64_t cval = (int64_t)(diff >> 48);
+        if ((uint64_t)cval >= rng) { err = true; return 0; }          // :283
+        uint32_t ft, d;
+        int scale;
+        if (!q15) {
+            ft = cdf[nsym - 1];
+            if (ft < 2 || ft > 32768) { err = true; return 0; }
+            scale = 15 - RangeEnc::ilog(ft - 1);
+            ft <<= scale;
+            if (ft > rng) { err = true; return 0; }
+            if (rng - ft >= ft) { ft <<= 1; scale++; }
+            d = rng - ft;
+        } else {
+            if (cdf[nsym - 1] != 32768 || rng < 32768) { err = true; return 0; }
+            d = rng - 32768; ft = 32768; scale = 0;
+        }
+        const uint32_t g = sat(2 * d, ft);
+        int64_t lim = cval >> 1;
+        if (cval - (int64_t)d > lim) lim = cval - (int64_t)d;
+        const int64_t third = (2 * cval + 1 - (int64_t)g) / 3;          // C division, toward zero
+        if (third > lim) lim = third;
+        lim >>= scale;
+        int ret = 0;
+        uint32_t u = 0, v;
+        for (v = cdf[ret]; (int64_t)v <= lim; v = cdf[++ret]) {
+            u = v;
+            if (ret + 1 >= nsym) { err = true; return 0; }
+        }
+        u <<= scale; v <<= scale;
+        const uint32_t bu = sat(u, g) >> 1, bv = sat(v, g) >> 1;
+        u = u + (u < g ? u : g) + (bu < d ? bu : d);
+        v = v + (v < g ? v : g) + (bv < d ? bv : d);
+        renorm(diff - ((uint64_t)u << 48), v - u);
+        return ret;
+    }
+    uint32_t bits(int num)
+    {
+        if (nwin < num) {
+            do {
+                if (epos == 0) { nwin = 16384; break; }
+                win |= (uint64_t)b[--epos] << nwin;
+                nwin += 8;
+            } while (nwin <= 64 - 8);
+        }
+        const uint32_t r = (uint32_t)(win & (((uint64_t)1 << num) - 1));
+        win >>= num; nwin -= num;
+        return r;
+    }
+    uint32_t uint_(uint32_t num)                                       // num > 16
+    {
+        num--;
+        const int bit = RangeEnc::ilog(num) - 4, adr = (int)(num >> bit) + 1;
+        uint16_t cdf[16];
+        for (int k = 0; k < adr; k++) cdf[k] = (uint16_t)((32768u * (uint32_t)(k + 1) + (uint32_t)adr / 2) / (uint32_t)adr);
+        cdf[adr - 1] = 32768;
+        uint32_t t = (uint32_t)decode(cdf, adr, true);
+        t = (t << bit) | bits(bit);
+        if (t <= num) return t;
+        err = true;
+        return num;
+    }
+    int adapt(uint16_t *cdf, int nsym, int inc)
+    {
+        const int r = decode(cdf, nsym, false);
+        if (err) return 0;
+        if (cdf[nsym - 1] + inc > 32767)
+            for (int i = 0; i < nsym; i++) cdf[i] = (uint16_t)((cdf[i] >> 1) + i + 1);
+        for (int i = r; i < nsym; i++) cdf[i] = (uint16_t)(cdf[i] + inc);
+        return r;
+    }
+    uint32_t golomb()                                                  // ffv2dec.c:76-86
+    {
+        uint32_t c = 1;
+        int guard = 0;
+        while (!bits(1)) {
+            c = (c << 1) | bits(1);
+            if (++guard > 40) { err = true; break; }
+        }
+        return c - 1;
+    }
+};
+
 int pixfmt_info(int pix_fmt, int *planes, int *depth)
 {
     switch (pix_fmt) {                    // allowed_pix_fmts, ffv2enc.c:596-601
@@ -545,6 +656,11 @@ struct ffv2amd_encoder {
     uint8_t *qh_frame[2] = { nullptr, nullptr }, *qd_frame[2] = { nullptr, nullptr };
     int32_t *qd_w[2] = { nullptr, nullptr };
     int64_t q_tag[2] = { 0, 0 };
+    // decoder-side check (ffv2amd_decode_frame)
+    int16_t *d_dec_pulses = nullptr;
+    float *d_dec_mag = nullptr;
+    int32_t *d_dec_c0 = nullptr, *d_dec_coef = nullptr;
+    uint8_t *d_dec_frame = nullptr;
     // wide (plain int32) T-stage of one frame: the rerun of frames the fast kernels refuse (ffv2_wide.hip)
     int32_t *d_wide_plane = nullptr, *d_wide_c0 = nullptr;
     int64_t *d_wide_en = nullptr;
@@ -709,6 +825,8 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     (void)hipFree(e->d_frame); (void)hipFree(e->d_pkt); (void)hipFree(e->d_meta); (void)hipFree(e->d_w1);
     (void)hipFree(e->d_inv_plane);
     (void)hipFree(e->d_wide_plane); (void)hipFree(e->d_wide_c0); (void)hipFree(e->d_wide_en);
+    (void)hipFree(e->d_dec_pulses); (void)hipFree(e->d_dec_mag); (void)hipFree(e->d_dec_c0); (void)hipFree(e->d_dec_coef);
+    (void)hipFree(e->d_dec_frame);
     (void)hipFree(e->d_coef_ws); (void)hipFree(e->d_y); (void)hipFree(e->d_pk_ws); (void)hipFree(e->d_sizes_ws);
     if (e->h_y) (void)hipHostFree(e->h_y);
     if (e->h_codes) (void)hipHostFree(e->h_codes);
@@ -1212,6 +1330,111 @@ int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t
         HIPCHK(hipMalloc(&e->d_inv_plane, sizeof(int32_t) * (size_t)g.nsx * 64 * g.nsy * 64 * g.planes * e->info.max_batch));
     HIPCHK(ffv2_launch_inverse(g, nframes, d_coef, e->d_inv_plane, (uint8_t *)d_frames_out, e->d_lds_scan,
                                (hipStream_t)stream));
+    return FFV2AMD_OK;
+}
+
+// ------------------------------------------------------------------
+// Decoder-side check of a finished packet, the shape of FATE's enc_dec (tests/fate-run.sh:188-210):
+// ffv2_decode_frame (ffv2dec.c:315-377).  The entropy layer is one serial chain per packet and is
+// parsed on the host (RangeDec above; symbol order of dequant_block, ffv2dec.c:100-136, with its one
+// pulses[] array per block-plane whose unread slots keep earlier bands' values); the scaling of the
+// pulses, the inverse T-stage (ffv2_inverse.hip) and coeffs_2_ref run on the device.  The band
+// magnitudes (pow, sqrt: ffv2dec.c:91-98,134) are the host libm's.  Not a product decoder: a
+// self check for the encoder and the PSNR line of the report.  PARITY UNPINNED.
+// ------------------------------------------------------------------
+int ffv2amd_decode_frame(ffv2amd_encoder *e, const uint8_t *pkt, size_t size, uint8_t *const data[4],
+                         const ptrdiff_t linesize[4], unsigned flags, int *qp_out)
+{
+    if (!e || !pkt || !data || !linesize) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    for (int p = 0; p < in.planes; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    const size_t nb = (size_t)in.block_planes;
+    std::vector<int16_t> pulses;
+    std::vector<float> mag;
+    std::vector<int32_t> c0;
+    std::vector<uint16_t> test;
+    std::vector<int> slot;
+    int qp = 0;
+    try {
+        pulses.assign(nb * 4096, 0); mag.assign(nb * 13, 0.f); c0.assign(nb, 0); slot.assign(4097, 0);
+        RangeDec d(pkt, size);
+        const int pix_fmt = (int)d.uint_(196);                           // ffv2dec.c:276
+        qp = (int)d.golomb();                                            // :277
+        if (d.err || pix_fmt != in.pix_fmt || qp < 0 || qp > 16384) return FFV2AMD_ERR_INVAL;
+        test.resize((size_t)13 * (qp > 0 ? qp : 1));
+        for (int r = 0; r < 13; r++)
+            for (int j = 0; j < qp; j++) test[(size_t)r * qp + j] = (uint16_t)(j + 1);
+        uint16_t subdiv[4] = { 32, 64, 96, 128 };
+        const int nsb = in.num_sb_x * in.num_sb_y;
+        for (int sb = 0; sb < nsb; sb++) {
+            if (d.adapt(subdiv, 4, 128) != 0 || d.err) return FFV2AMD_ERR_INVAL;   // the encoder never splits
+            (void)d.bits(4);                                             // tx type
+            for (int p = 0; p < in.planes; p++) {
+                const size_t bp = (size_t)sb * in.planes + p;
+                std::fill(slot.begin(), slot.end(), 0);                  // int pulses[4096] = { 0 }
+                int32_t v = (int32_t)d.golomb();
+                if (v) v = (int32_t)((uint32_t)v * (uint32_t)(1 - 2 * (int)d.bits(1)));
+                c0[bp] = v;
+                for (int b = 0; b < 13; b++) {
+                    const int lo = 1 + BANDS_START[b], len = BANDS_START[b + 1] - BANDS_START[b];
+                    const float cg = (float)d.golomb();
+                    float m = (float)pow((double)(cg * 1), (double)1.5f);         // gain_expand(cg, 1, 1.5f)
+                    int cnt = 0, pcnt = 0;
+                    for (int j = 0; j < len; j++) {
+                        if (pcnt >= qp) break;
+                        int q = d.adapt(&test[(size_t)b * qp], qp, 64);
+                        if (q) q *= 1 - 2 * (int)d.bits(1);
+                        slot[j] = q;
+                        pcnt += q < 0 ? -q : q;
+                        cnt += q * q;
+                    }
+                    if (d.err) return FFV2AMD_ERR_INVAL;
+                    mag[bp * 13 + b] = (float)((double)m / sqrt((double)cnt));    // mag /= sqrt(cnt)
+                    for (int j = 0; j < len && lo + j < 4096; j++)
+                        pulses[bp * 4096 + lo + j] = (int16_t)slot[j];
+                }
+            }
+        }
+    } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    if (qp_out) *qp_out = qp;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const FFV2Geom &g = e->geom;
+    if (!e->d_dec_pulses) {
+        HIPCHK(hipMalloc(&e->d_dec_pulses, sizeof(int16_t) * 4096 * nb));
+        HIPCHK(hipMalloc(&e->d_dec_mag, sizeof(float) * 13 * nb));
+        HIPCHK(hipMalloc(&e->d_dec_c0, sizeof(int32_t) * nb));
+        HIPCHK(hipMalloc(&e->d_dec_coef, sizeof(int32_t) * 4096 * nb));
+        HIPCHK(hipMalloc(&e->d_dec_frame, in.frame_stride));
+    }
+    if (!e->d_inv_plane)
+        HIPCHK(hipMalloc(&e->d_inv_plane, sizeof(int32_t) * (size_t)g.nsx * 64 * g.nsy * 64 * g.planes * e->info.max_batch));
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->d_dec_pulses, pulses.data(), sizeof(int16_t) * pulses.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_dec_mag, mag.data(), sizeof(float) * mag.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->d_dec_c0, c0.data(), sizeof(int32_t) * c0.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(ffv2_launch_dequant(e->d_dec_pulses, e->d_dec_mag, e->d_dec_c0, e->d_dec_coef, (long long)nb, s));
+    HIPCHK(ffv2_launch_inverse(g, 1, e->d_dec_coef, e->d_inv_plane, e->d_dec_frame, e->d_lds_scan, s));
+    const size_t bps = in.depth > 8 ? 2 : 1;
+    for (int p = 0; p < in.planes; p++)
+        HIPCHK(hipMemcpy2DAsync(data[p], (size_t)linesize[p], e->d_dec_frame + (size_t)p * in.plane_stride, in.row_pitch,
+                                (size_t)in.width * bps, (size_t)in.height, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flags & FFV2AMD_DECODE_GRID) {
+        // the reference decoder's `#define DEBUGGING` (ffv2dec.c:88,258-273): first row and column of every superblock
+        for (int p = 0; p < in.planes; p++) {
+            const int v = ((p ? 0 : -2048) + 2048) >> (12 - in.depth);
+            for (int y = 0; y < in.height; y++) {
+                uint8_t *row = data[p] + (ptrdiff_t)y * linesize[p];
+                for (int x = 0; x < in.width; x++) {
+                    if ((x & 63) && (y & 63)) continue;
+                    if (bps == 1) row[x] = (uint8_t)v;
+                    else { const uint16_t w = (uint16_t)v; memcpy(row + 2 * x, &w, 2); }
+                }
+            }
+        }
+    }
     return FFV2AMD_OK;
 }
 

@@ -167,7 +167,36 @@ __global__ __launch_bounds__(256) void ffv2_ipix_kernel(const InvArgs a)
     else reinterpret_cast<uint16_t *>(row)[xx] = (uint16_t)v;
 }
 
+// dequant_block's last loop (ffv2dec.c:135-136): coefficient = pulse * mag, stored to int32 as the
+// reference binary does on x86-64 (cvttss2si: truncation; NaN and out-of-range -> 0x80000000, which is
+// what every coefficient of a qp == 0 packet becomes: mag = gain / sqrt(0)).  pulses: the value the
+// decoder's pulses[] holds for each coding position when its band is scaled (stale slots included),
+// worked out by the host's entropy parse; mag: per block-plane and band, computed on the host with its
+// own pow / sqrt.  Coding index 0 is the "DC" slot, passed through.
+__global__ __launch_bounds__(256) void ffv2_dequant_kernel(const int16_t *pulses, const float *mag, const int32_t *c0,
+                                                           int32_t *coef, long long nbp)
+{
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nbp * 4096) return;
+    const long long bp = id >> 12;
+    const int q = (int)(id & 4095);
+    if (q == 0) { coef[id] = c0[bp]; return; }
+    // band of coding index q: starts 1 + {0,15,23,31,63,95,127,255,383,511,1023,1535,2047} (ffv2.c:100-120)
+    const int t = q - 1;
+    const int band = (t >= 15) + (t >= 23) + (t >= 31) + (t >= 63) + (t >= 95) + (t >= 127) + (t >= 255) + (t >= 383) +
+                     (t >= 511) + (t >= 1023) + (t >= 1535) + (t >= 2047);
+    const float v = (float)pulses[id] * mag[bp * 13 + band];
+    coef[id] = (v > -2147483904.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000;
+}
+
 }  // namespace
+
+hipError_t ffv2_launch_dequant(const int16_t *pulses, const float *mag, const int32_t *c0, int32_t *coef, long long nbp,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(ffv2_dequant_kernel, dim3((unsigned)((nbp * 4096 + 255) / 256)), dim3(256), 0, s, pulses, mag, c0, coef, nbp);
+    return hipGetLastError();
+}
 
 hipError_t ffv2_launch_inverse(const FFV2Geom &g, int nframes, const int32_t *coef, int32_t *plane,
                                uint8_t *frames, const uint16_t *lds_scan, hipStream_t s)

@@ -58,6 +58,9 @@ void ffv2_tstage_force_variant(int mode);   // tests: 0 one-block kernel, 1 colu
 const char *ffv2_tstage_kernel_name(const FFV2Geom &g, int nframes, bool coef_writeback);   // which T-stage kernel a launch would use
 hipError_t ffv2_launch_inverse(const FFV2Geom &g, int nframes, const int32_t *coef, int32_t *plane,
                                uint8_t *frames, const uint16_t *lds_scan, hipStream_t s);
+// decoder-side dequantisation (ffv2dec.c:135-136) in front of ffv2_launch_inverse: see ffv2_inverse.hip
+hipError_t ffv2_launch_dequant(const int16_t *pulses, const float *mag, const int32_t *c0, int32_t *coef, long long nbp,
+                               hipStream_t s);
 // Per-block-plane index into a frame's compact symbol stream (qp > 0): the int8 pulses the
 // range coder will read, band after band, start at stream[offset]; count[b] of them in band b.
 struct FFV2SymRec {

@@ -105,6 +105,22 @@ class FFV2Encoder:
                                                    C.c_void_p(stream)), "ffv2amd_tstage_device")
         return coef, en
 
+    def decode(self, packet, grid=False):
+        """Decoder-side check (ffv2dec.c:315-377): packet -> ((P,H,W) samples, qp).  grid: with the reference
+        decoder's DEBUGGING overwrite of every superblock's first row and column."""
+        i = self.info
+        out = np.zeros((i.planes, i.height, i.width), self.dtype)
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(i.planes):
+            data[p] = out[p].ctypes.data
+            ls[p] = out[p].strides[0]
+        buf = np.frombuffer(bytes(packet), np.uint8)
+        qp = C.c_int(-1)
+        _lib.check(self._lib.ffv2amd_decode_frame(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, data, ls,
+                                                  1 if grid else 0, C.byref(qp)), "ffv2amd_decode_frame")
+        return out, qp.value
+
     def tstage_wide(self, d_frame):
         """One frame (torch uint8 (frame_stride,) or (1, frame_stride)) through the plain-int32 T-stage
         (ffv2_wide.hip): any 16-bit sample.  -> (coef (block_planes, 4096) int32, energy (block_planes, 13) int64)."""

@@ -235,6 +235,20 @@ int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d
 int  ffv2amd_inverse_tstage_device(ffv2amd_encoder *enc, int nframes, const int32_t *d_coef,
                                    void *d_frames_out, void *stream);
 
+/* Decoder-side check of a finished packet, the shape of FATE's enc_dec (reference tests/fate-run.sh:188-210):
+ * ffv2_decode_frame (ffv2dec.c:315-377) -- entropy layer parsed on the host (daala_entropy.c:273-326,
+ * 413-425 in the symbol order of dequant_block, ffv2dec.c:100-136), scaling of the pulses, inverse
+ * T-stage and coeffs_2_ref on the device -- into the caller's planes (the encoder's geometry and
+ * pix_fmt; the packet's header must agree).  Reproduces the reference decoder as it is, quirks
+ * included: at qp == 0 it divides by sqrt(0) and every coefficient becomes 0x80000000 (ffv2dec.c:134-136),
+ * unread pulse slots carry over between bands.  FFV2AMD_DECODE_GRID: also its `#define DEBUGGING`
+ * overwrite of each superblock's first row and column (:258-273; the text overlay of 8-bit pictures
+ * contains the decoding time and is not reproducible).  *qp_out: the packet's qp.  A self check and the
+ * PSNR line of tools/fate_report.py, not a product decoder.  PARITY UNPINNED. */
+#define FFV2AMD_DECODE_GRID 1u
+int  ffv2amd_decode_frame(ffv2amd_encoder *enc, const uint8_t *packet, size_t size, uint8_t *const data[4],
+                          const ptrdiff_t linesize[4], unsigned flags, int *qp_out);
+
 /* Test hook: the device PVQ search on `count` float vectors of N <= 2049 elements
  * (d_X[v*stride + i]); writes int16 pulses to d_y[v*stride + i]. */
 int  ffv2amd_pvq_search_device(ffv2amd_encoder *enc, const float *d_X, int stride, int N, int K,

@@ -806,3 +806,264 @@ end:
     oframe_free(&f);
     return ret;
 }
+
+/* ------------------------------------------------------------------ */
+/* Decoder side (libavcodec/ffv2dec.c over daala_entropy.c) -- what the FATE-style     */
+/* enc/dec report (tests/fate-run.sh:188-210) decodes the encoder's packets with.       */
+/* Restated with the decoder's own quirks, because they are its observable behaviour:   */
+/*  * dequant_block keeps ONE pulses[4096] per block-plane, zeroed once and indexed from */
+/*    0 by every band (ffv2dec.c:103,118-136): slots a band does not read (its loop      */
+/*    stops once qp pulses are in) still hold what EARLIER bands put there, and are      */
+/*    scaled into this band's coefficients all the same.                                 */
+/*  * mag /= sqrt(cnt) (:134): at qp == 0 no pulse is ever read, cnt = 0, mag = inf or   */
+/*    NaN, every coefficient 0 * mag = NaN, and the float -> int32 store of NaN is what  */
+/*    x86's cvttss2si makes of it, 0x80000000 (UB in C; spelt out below).                */
+/*  * the last band is 2049 long: its last write lands one int32 past temp[] (:136);     */
+/*    dropped here.                                                                      */
+/*  * #define DEBUGGING (:88) is on in the reference: decode_sbs overwrites row 0 / column */
+/*    0 of every superblock with -2048 (plane 0) or 0 (:258-273), and for 8-bit pictures */
+/*    ffv2_decode_frame draws a text overlay that contains the decoding time (:361-372). */
+/*    The grid is reproduced on request (FFV2O_DEC_GRID); the text is not reproducible.  */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *b;
+    size_t n, pos, epos;      /* range bytes read forward from pos, raw bytes backward from epos */
+    uint64_t diff;
+    uint32_t rng;
+    int cnt;
+    uint64_t win;
+    int nwin;
+    int err;
+} ODec;
+
+#define ODEC_ABUNDANCE 16384                                    /* DAALAENT_BIT_ABUNDANCE */
+
+static void odec_fill(ODec *d)                                  /* daala_entropy.c:79-95 */
+{
+    int i = 64 - 9 - (d->cnt + 15);
+    for (; i >= 0 && d->pos < d->n; i -= 8, d->pos++) {
+        d->diff |= (uint64_t)d->b[d->pos] << i;
+        d->cnt += 8;
+    }
+    if (d->pos >= d->n)
+        d->cnt = ODEC_ABUNDANCE;
+}
+
+static void odec_init(ODec *d, const uint8_t *buf, size_t size) /* :564-578 */
+{
+    memset(d, 0, sizeof(*d));
+    d->b = buf; d->n = size; d->epos = size;
+    d->rng = 0x8000; d->cnt = -15;
+    odec_fill(d);
+}
+
+static void odec_renorm(ODec *d, uint64_t diff, uint32_t rng)   /* :97-105 */
+{
+    const int i = 16 - ilog(rng);
+    d->diff = diff << i;
+    d->rng = rng << i;
+    if ((d->cnt -= i) < 0)
+        odec_fill(d);
+}
+
+static uint32_t osat(uint32_t a, uint32_t b) { return a - (a < b ? a : b); }   /* DAALAENT_SAT */
+
+/* daalaent_decode_cdf (:273-326), CDF_UNSCALED (q15 == 0) or CDF_Q15 */
+static int odec_cdf(ODec *d, const uint16_t *cdf, int n, int q15)
+{
+    uint32_t rng = d->rng, ft, dd, g;
+    int scale, ret = 0;
+    const uint64_t diff = d->diff;
+    const int64_t cval = (int64_t)(diff >> 48);
+    if ((uint64_t)cval >= rng) { d->err = 1; return 0; }         /* :283 av_assert0 */
+    if (!q15) {
+        ft = cdf[n - 1];
+        if (ft < 2 || ft > 32768) { d->err = 1; return 0; }
+        scale = 15 - ilog(ft - 1);
+        ft <<= scale;
+        if (ft > rng) { d->err = 1; return 0; }
+        if (rng - ft >= ft) { ft <<= 1; scale++; }
+        dd = rng - ft;
+    } else {
+        if (cdf[n - 1] != 32768 || rng < 32768) { d->err = 1; return 0; }
+        dd = rng - 32768; ft = 32768; scale = 0;
+    }
+    g = osat(2 * dd, ft);
+    {
+        int64_t a = cval >> 1, b = cval - (int64_t)dd, c = (2 * cval + 1 - (int64_t)g) / 3;   /* C division: toward zero */
+        int64_t lim = a > b ? a : b;
+        uint32_t u = 0, v;
+        if (c > lim) lim = c;
+        lim >>= scale;
+        for (v = cdf[ret]; (int64_t)v <= lim; v = cdf[++ret]) {
+            u = v;
+            if (ret + 1 >= n) { d->err = 1; return 0; }          /* the reference would run off the row */
+        }
+        u <<= scale; v <<= scale;
+        {
+            const uint32_t bu = osat(u, g) >> 1, bv = osat(v, g) >> 1;
+            u = u + (u < g ? u : g) + (bu < dd ? bu : dd);
+            v = v + (v < g ? v : g) + (bv < dd ? bv : dd);
+        }
+        odec_renorm(d, diff - ((uint64_t)u << 48), v - u);
+    }
+    return ret;
+}
+
+static uint32_t odec_bits(ODec *d, int num)                     /* :200-224 */
+{
+    int avail = d->nwin;
+    uint64_t win = d->win;
+    uint32_t ret;
+    if (avail < num) {
+        do {
+            if (d->epos == 0) { avail = ODEC_ABUNDANCE; break; }
+            win |= (uint64_t)d->b[--d->epos] << avail;
+            avail += 8;
+        } while (avail <= 64 - 8);
+    }
+    ret = (uint32_t)(win & (((uint64_t)1 << num) - 1));
+    d->win = win >> num;
+    d->nwin = avail - num;
+    return ret;
+}
+
+static uint32_t odec_uint(ODec *d, uint32_t num)                /* :382-396, num > 16 */
+{
+    uint16_t cdf[16];
+    int bit, adr, t;
+    num--;
+    bit = ilog(num) - 4;
+    adr = (int)(num >> bit) + 1;
+    for (int k = 0; k < adr; k++)                               /* daalatab.c:50-64, uniform Q15 rows */
+        cdf[k] = (uint16_t)((32768u * (uint32_t)(k + 1) + (uint32_t)adr / 2) / (uint32_t)adr);
+    cdf[adr - 1] = 32768;
+    t = odec_cdf(d, cdf, adr, 1);
+    t = (int)(((uint32_t)t << bit) | odec_bits(d, bit));
+    if ((uint32_t)t <= num) return (uint32_t)t;
+    d->err = 1;
+    return num;
+}
+
+static int odec_adapt(ODec *d, uint16_t *cdf, int n, int inc)   /* :413-425 */
+{
+    const int r = odec_cdf(d, cdf, n, 0);
+    if (d->err) return 0;
+    if (cdf[n - 1] + inc > 32767)
+        for (int i = 0; i < n; i++) cdf[i] = (uint16_t)((cdf[i] >> 1) + i + 1);
+    for (int i = r; i < n; i++) cdf[i] = (uint16_t)(cdf[i] + inc);
+    return r;
+}
+
+static uint32_t odec_golomb(ODec *d)                            /* ffv2dec.c:76-86 */
+{
+    uint32_t c = 1;
+    int guard = 0;
+    while (!odec_bits(d, 1)) {
+        c = (c << 1) | odec_bits(d, 1);
+        if (++guard > 40) { d->err = 1; break; }                 /* a truncated packet reads zeros for ever */
+    }
+    return c - 1;
+}
+
+/* float -> int32 as the reference binary stores it on x86-64 (cvttss2si): truncation, and the
+ * "integer indefinite" 0x80000000 for NaN and for everything outside int32 */
+static int32_t f2i_x86(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f))
+        return INT32_MIN;
+    return (int32_t)v;
+}
+
+/* Entropy layer + dequant_block of one packet: coding-order coefficients [nblk][4096]. */
+int ffv2o_decode_coefficients(const uint8_t *pkt, size_t size, int width, int height, int expect_pix_fmt,
+                              int *pix_fmt_out, int *qp_out, int32_t *coef)
+{
+    ODec d;
+    int planes, depth;
+    if (!pkt || !coef || width <= 0 || height <= 0) return FFV2O_ERR_PIXFMT;
+    odec_init(&d, pkt, size);
+    const int pix_fmt = (int)odec_uint(&d, 196);                 /* ffv2dec.c:276 */
+    const int qp = (int)odec_golomb(&d);                         /* :277 */
+    if (d.err || ffv2o_pixfmt_info(pix_fmt, &planes, &depth) < 0 || qp < 0 || qp > 32767)
+        return FFV2O_ERR_ABORT;
+    if (pix_fmt_out) *pix_fmt_out = pix_fmt;
+    if (qp_out) *qp_out = qp;
+    if (pix_fmt != expect_pix_fmt) return FFV2O_ERR_PIXFMT;      /* coef[] was sized for expect_pix_fmt's planes */
+    const int nsx = (width + SB - 1) / SB, nsy = (height + SB - 1) / SB;
+    uint16_t subdiv[4] = { 32, 64, 96, 128 };                    /* daalaent_cdf_alloc(1,4,128,0,2,0), reset :332 */
+    uint16_t *test = malloc(sizeof(uint16_t) * 13 * (size_t)(qp > 0 ? qp : 1));
+    int *pulses = malloc(sizeof(int) * 4097);
+    if (!test || !pulses) { free(test); free(pulses); return FFV2O_ERR_NOMEM; }
+    for (int r = 0; r < 13; r++)
+        for (int j = 0; j < qp; j++) test[(size_t)r * qp + j] = (uint16_t)(j + 1);   /* daalaent_cdf_alloc(13,qp,64,0,6,0) */
+    int rc = 0;
+    for (int sb = 0; sb < nsx * nsy && !rc; sb++) {
+        const int split = odec_adapt(&d, subdiv, 4, 128);        /* decode_block_rec :215 */
+        if (d.err || split != 0) { rc = FFV2O_ERR_ABORT; break; } /* the encoder never splits (ffv2enc.c:272) */
+        (void)odec_bits(&d, 4);                                  /* tx type, :162 */
+        for (int p = 0; p < planes && !rc; p++) {
+            int32_t *dst = coef + ((size_t)sb * planes + p) * 4096;
+            memset(dst, 0, sizeof(int32_t) * 4096);
+            memset(pulses, 0, sizeof(int) * 4097);               /* int pulses[4096] = { 0 }, once per block-plane */
+            {
+                const uint32_t c0 = odec_golomb(&d);             /* :109-111: dctcoef = uint32, then *= +-1 */
+                int32_t v = (int32_t)c0;
+                if (v) v = (int32_t)((uint32_t)v * (uint32_t)(1 - 2 * (int)odec_bits(&d, 1)));
+                dst[0] = v;
+            }
+            for (int b = 0; b < NUM_BANDS; b++) {
+                const int lo = 1 + BANDS_START[b], len = BANDS_START[b + 1] - BANDS_START[b];
+                /* gain_expand(cg, 1, 1.5f): (float)pow((double)(cg * 1), (double)1.5f), cg a float */
+                const float cg = (float)odec_golomb(&d);
+                float mag = (float)pow((double)(cg * 1), (double)1.5f);
+                int cnt = 0, pcnt = 0;
+                for (int j = 0; j < len; j++) {
+                    if (pcnt >= qp) break;
+                    int q = odec_adapt(&d, test + (size_t)b * qp, qp, 64);
+                    if (q) q *= 1 - 2 * (int)odec_bits(&d, 1);
+                    pulses[j] = q;
+                    pcnt += q < 0 ? -q : q;
+                    cnt += q * q;
+                }
+                if (d.err) { rc = FFV2O_ERR_ABORT; break; }
+                mag = (float)((double)mag / sqrt((double)cnt));  /* mag /= sqrt(cnt): float /= double */
+                for (int j = 0; j < len && lo + j < 4096; j++)
+                    dst[lo + j] = f2i_x86((float)pulses[j] * mag);
+            }
+        }
+    }
+    free(test);
+    free(pulses);
+    return rc;
+}
+
+/* ffv2_decode_frame (ffv2dec.c:315-377): packet -> picture planes of the packet's own pix_fmt
+ * (which must be expect_pix_fmt: the caller sized the planes for it).  flags & FFV2O_DEC_GRID:
+ * the DEBUGGING overwrite of every superblock's first row and column (:258-273). */
+int ffv2o_decode_frame(const uint8_t *pkt, size_t size, int width, int height, int expect_pix_fmt, int flags,
+                       uint8_t *const data[4], const ptrdiff_t linesize[4], int *qp_out)
+{
+    int planes, depth, pix_fmt = -1;
+    if (ffv2o_pixfmt_info(expect_pix_fmt, &planes, &depth) < 0) return FFV2O_ERR_PIXFMT;
+    const int nsx = (width + SB - 1) / SB, nsy = (height + SB - 1) / SB;
+    int32_t *coef = malloc(sizeof(int32_t) * 4096 * (size_t)nsx * nsy * planes);
+    if (!coef) return FFV2O_ERR_NOMEM;
+    int rc = ffv2o_decode_coefficients(pkt, size, width, height, expect_pix_fmt, &pix_fmt, qp_out, coef);
+    if (!rc) rc = ffv2o_inverse_tstage(coef, width, height, pix_fmt, data, linesize);
+    free(coef);
+    if (!rc && (flags & FFV2O_DEC_GRID)) {
+        for (int p = 0; p < planes; p++) {
+            const int v = ((p ? 0 : -2048) + 2048) >> (12 - depth);
+            for (int y = 0; y < height; y++) {
+                uint8_t *row = data[p] + (ptrdiff_t)y * linesize[p];
+                for (int x = 0; x < width; x++) {
+                    if ((x & 63) && (y & 63)) continue;
+                    if (depth == 8) row[x] = (uint8_t)v;
+                    else { const uint16_t w = (uint16_t)v; memcpy(row + 2 * x, &w, 2); }
+                }
+            }
+        }
+    }
+    return rc;
+}

@@ -83,6 +83,18 @@ int ffv2o_encode_frame(const uint8_t *const data[4], const ptrdiff_t linesize[4]
                        const int32_t *W,
                        uint8_t *out, size_t out_cap, size_t *out_size);
 
+/* Decoder side (ffv2dec.c:76-136,275-280,315-377 over daala_entropy.c:79-105,200-224,273-326,382-396,
+ * 413-425,564-578), for the FATE-style encode -> decode report: the entropy layer and dequant_block of
+ * one packet -> coding-order coefficients [nblk][4096]; and the whole frame.  Reproduces the decoder's
+ * quirks (stale pulses between bands, mag / sqrt(0) at qp 0 with x86's NaN -> int32 store), see the .c.
+ * FFV2O_DEC_GRID: also the reference's `#define DEBUGGING` overwrite of each superblock's first row and
+ * column.  PARITY UNPINNED (the reference holds no decoded-output hash for FFV2). */
+#define FFV2O_DEC_GRID 1
+int ffv2o_decode_coefficients(const uint8_t *pkt, size_t size, int width, int height, int expect_pix_fmt,
+                              int *pix_fmt_out, int *qp_out, int32_t *coef);
+int ffv2o_decode_frame(const uint8_t *pkt, size_t size, int width, int height, int expect_pix_fmt, int flags,
+                       uint8_t *const data[4], const ptrdiff_t linesize[4], int *qp_out);
+
 /* PVQ search restating ff_pvq_search_exact_avx (celt_pvq_search.asm:214-368). */
 float ffv2o_pvq_search(float *X, int *y, int K, int N);
 

@@ -74,6 +74,39 @@ class Oracle:
             raise RuntimeError("oracle error %d" % r)
         return out[:size.value].tobytes()
 
+    def decode_coefficients(self, pkt, pix_fmt, H, Wd):
+        """Entropy layer + dequant_block of the reference DECODER (ffv2dec.c:100-136): packet ->
+        (coef [nsb*P][4096] int32 coding order, qp).  Raises on a packet the decoder would choke on."""
+        P = 1 if pix_fmt == "gray" else 3
+        nsb = ((Wd + 63) // 64) * ((H + 63) // 64)
+        coef = np.zeros((nsb * P, 4096), np.int32)
+        buf = np.frombuffer(bytes(pkt), np.uint8)
+        pf, qp = C.c_int(-1), C.c_int(-1)
+        r = self.lib.ffv2o_decode_coefficients(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.c_int(Wd), C.c_int(H),
+                                               C.c_int(PIX[pix_fmt]), C.byref(pf), C.byref(qp), coef.ctypes.data_as(C.c_void_p))
+        if r < 0 or pf.value != PIX[pix_fmt]:
+            raise RuntimeError("oracle decoder error %d (pix_fmt %d)" % (r, pf.value))
+        return coef, qp.value
+
+    def decode(self, pkt, pix_fmt, H, Wd, grid=False):
+        """ffv2_decode_frame of the reference DECODER: packet -> ((P,H,W) samples, qp).  grid: with the
+        reference's DEBUGGING overwrite of every superblock's first row and column."""
+        P = 1 if pix_fmt == "gray" else 3
+        depth = {"gray": 8, "yuv444p": 8, "gbrp": 8}.get(pix_fmt, 12 if "12" in pix_fmt else 10)
+        out = np.zeros((P, H, Wd), np.uint8 if depth == 8 else np.dtype("<u2"))
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p in range(P):
+            data[p] = out[p].ctypes.data
+            ls[p] = out[p].strides[0]
+        buf = np.frombuffer(bytes(pkt), np.uint8)
+        qp = C.c_int(-1)
+        r = self.lib.ffv2o_decode_frame(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size), C.c_int(Wd), C.c_int(H),
+                                        C.c_int(PIX[pix_fmt]), C.c_int(1 if grid else 0), data, ls, C.byref(qp))
+        if r < 0:
+            raise RuntimeError("oracle decoder error %d" % r)
+        return out, qp.value
+
     def tstage(self, frame, pix_fmt):
         frame, data, ls = self._planes(frame)
         P, H, Wd = frame.shape

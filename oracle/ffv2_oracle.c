@@ -735,7 +735,14 @@ static int quant_block(OEnt *e, OCdf *test_cdf, const int32_t c[4096], int32_t W
         int64_t igain = 0;
         float fgain;
         for (int j = 0; j < len; j++) {
-            int32_t v = lo + j < 4096 ? c[lo + j] : W;      /* temp2[4096]: SURVEY.md 8/A9 */
+            /* temp2[4096]: SURVEY.md 8/A9.  The reference reads that word TWICE -- here for the energy
+             * (ffv2enc.c:163-164) and again below for the normalised vector (:168-169).  One W serves both
+             * reads in this model: it covers the stack layouts in which nothing writes the slot in between
+             * (the survey's gcc build).  In a layout where the slot IS one of quant_block's own scratch
+             * arrays (AMD clang: norm_coeffs[0], stored by the loop at :168 before its last iteration reads
+             * src_c[2048]) the second read sees float bits instead, and that build aborts on every qp > 0
+             * input -- not modelled, there is no output to match. */
+            int32_t v = lo + j < 4096 ? c[lo + j] : W;
             igain += (int64_t)v * v;
         }
         fgain = sqrtf((float)igain) + FLT_EPSILON;

@@ -17,7 +17,7 @@ EXPORTS = [
     "ffv2amd_ring_send_420", "ffv2amd_tstage_wide_device", "ffv2amd_decode_frame", "ffv2amd_qp_send_frame", "ffv2amd_qp_receive_packet", "ffv2amd_qp_pending", "ffv2amd_encoder_set_device_coder",
     "ffv2amd_frame_bytes_420", "ffv2amd_upconvert_420_device", "ffv2amd_encode_frame_420",
     "ffv2amd_lanecoder_open", "ffv2amd_lanecoder_close", "ffv2amd_lanecoder_bytes_per_frame", "ffv2amd_lanecoder_encode",
-    "ffv2amd_lanecoder_submit", "ffv2amd_lanecoder_finish", "ffv2amd_lanecoder_finish_packed", "ffv2amd_lanecoder_stats",
+    "ffv2amd_lanecoder_submit", "ffv2amd_lanecoder_finish", "ffv2amd_lanecoder_finish_packed", "ffv2amd_lanecoder_stats", "ffv2amd_debug_lanecoder_window",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
     "ffv2amd_codec_send_frame", "ffv2amd_codec_receive_packet", "ffv2amd_packet_unref", "ffv2amd_codec_encode_yuv420",
@@ -121,6 +121,8 @@ def load():
     lib.ffv2amd_lanecoder_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.ffv2amd_lanecoder_finish_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ffv2amd_lanecoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    lib.ffv2amd_debug_lanecoder_window.argtypes = [C.c_uint32]
+    lib.ffv2amd_debug_lanecoder_window.restype = None
     lib.ffv2amd_lanecoder_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.ffv2amd_frame_bytes_420.argtypes = [C.c_void_p]

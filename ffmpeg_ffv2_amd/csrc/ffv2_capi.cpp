@@ -706,7 +706,11 @@ struct ffv2amd_encoder {
             bool busy = false;
         } set[3];
         int nsets = 2;                   // calls in flight (2 or 3): how many of the sets are in use
-        hipStream_t back = nullptr, copy = nullptr;
+        hipStream_t back = nullptr, copy = nullptr, cdfs = nullptr;       // chain + finish | packets out | cdf windows
+        hipEvent_t ev_cdf[2] = { nullptr, nullptr }, ev_chain[2] = { nullptr, nullptr };   // per record buffer: filled / read
+        hipEvent_t ev_backdone = nullptr;                                   // the previous call's back has let go of the shared scratch
+        bool backdone_valid = false;
+        uint32_t maxsym16 = 0, window = 0;                                  // symbols per frame at most; symbols per window
         unsigned sub = 0, fin = 0;
         float last_chain_ms = 0, last_back_ms = 0;   // of the call finished last (ffv2amd_lanecoder_stats)
         uint32_t last_symbols0 = 0;
@@ -1470,6 +1474,20 @@ int ffv2amd_pvq_search_device(ffv2amd_encoder *e, const float *d_X, int stride, 
 // without waiting for a finish: the period of back-to-back calls falls from (back + front + copy) / 2 to
 // max(back, front).
 // ------------------------------------------------------------------
+// Symbols of every frame's coding order that cdf and chain work on at a time (ffv2_lanecoder.hip,
+// "windows"): the records exist for two windows only.  Default 2^18 symbols = 4 MB of records per
+// frame; FFV2AMD_LC_WINDOW or ffv2amd_debug_lanecoder_window() override it (tests use tiny windows).
+static uint32_t g_lc_window = 0;
+static uint32_t lanecoder_window(size_t maxsym16)
+{
+    static const uint32_t env = getenv("FFV2AMD_LC_WINDOW") ? (uint32_t)strtoul(getenv("FFV2AMD_LC_WINDOW"), nullptr, 10) : 0u;
+    uint64_t w = g_lc_window ? g_lc_window : env ? env : (1u << 18);
+    w = (w + 15) / 16 * 16;
+    if (w < 16) w = 16;
+    if (w > maxsym16) w = maxsym16;
+    return (uint32_t)w;
+}
+
 static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nsets)
 {
     auto &lc = e->lc;
@@ -1488,12 +1506,17 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     a.width = width;
     const size_t groups = (F + width - 1) / width;
     const size_t maxsym = ((1 + nsb + nb * 4097) + 15) / 16 * 16;
-    a.group_stride = maxsym * (size_t)width;                       // uint2 per group
+    if (maxsym >= ((size_t)1 << 32)) return FFV2AMD_ERR_INVAL;
+    lc.maxsym16 = (uint32_t)maxsym;
+    lc.window = lanecoder_window(maxsym);
+    a.group_stride = (size_t)lc.window * (size_t)width;            // uint2 per group and window
+    a.buf_stride = a.group_stride * groups;
     a.row_stride = (nb * 4097 + 255) / 256 * 256;
     a.raw_words = (uint32_t)(pcap / 4 + 4);
     a.wcap = (uint32_t)(pcap / 2 + 32);
     a.packet_stride = pcap;
-    bool ok = dev(&a.recs, sizeof(uint2) * a.group_stride * groups) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
+    bool ok = dev(&a.recs, sizeof(uint2) * a.buf_stride * 2) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
+           && dev(&a.cdfstate, sizeof(uint32_t) * 68 * 13 * F)
            && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.fin, sizeof(uint4) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
     for (int k = 0; k < nsets; k++) {
         auto &q = lc.set[k];
@@ -1521,6 +1544,12 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     }
     HIPCHK(hipStreamCreateWithFlags(&lc.back, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&lc.copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&lc.cdfs, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipEventCreateWithFlags(&lc.ev_cdf[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&lc.ev_chain[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&lc.ev_backdone, hipEventDisableTiming));
     // the symbols that carry no data: "no split" of every superblock (ffv2enc.c:222; the CDF of
     // daala_entropy.h:140-161 advances by itself), the range-coded part of the header (ffv2enc.c:449)
     std::vector<uint2> split;
@@ -1547,6 +1576,12 @@ static void lanecoder_free(ffv2amd_encoder *e)
     auto &lc = e->lc;
     if (lc.back) { (void)hipStreamSynchronize(lc.back); (void)hipStreamDestroy(lc.back); }
     if (lc.copy) { (void)hipStreamSynchronize(lc.copy); (void)hipStreamDestroy(lc.copy); }
+    if (lc.cdfs) { (void)hipStreamSynchronize(lc.cdfs); (void)hipStreamDestroy(lc.cdfs); }
+    for (int k = 0; k < 2; k++) {
+        if (lc.ev_cdf[k]) (void)hipEventDestroy(lc.ev_cdf[k]);
+        if (lc.ev_chain[k]) (void)hipEventDestroy(lc.ev_chain[k]);
+    }
+    if (lc.ev_backdone) (void)hipEventDestroy(lc.ev_backdone);
     for (void *p : lc.allocs) (void)hipFree(p);
     lc.allocs.clear();
     for (auto &q : lc.set) {
@@ -1584,6 +1619,8 @@ int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t pack
     return r;
 }
 
+void ffv2amd_debug_lanecoder_window(uint32_t symbols) { g_lc_window = symbols; }
+
 int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
@@ -1600,7 +1637,9 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet
     const ffv2amd_info &in = e->info;
     if (packet_cap == 0 || packet_cap > in.packet_cap_qp) packet_cap = in.packet_cap_qp;
     const size_t nb = (size_t)in.block_planes, nsb = (size_t)in.num_sb_x * in.num_sb_y;
-    const size_t shared = ((1 + nsb + nb * 4097) + 15) / 16 * 16 * sizeof(uint2) + packet_cap * 2 + 256;
+    const size_t maxsym = ((1 + nsb + nb * 4097) + 15) / 16 * 16;
+    // records of two windows, code words, the rows' and the frame's state between windows
+    const size_t shared = (size_t)lanecoder_window(maxsym) * 2 * sizeof(uint2) + packet_cap * 2 + 13 * 68 * 4 + 256;
     const size_t per_set = (nb * 4097 + 255) / 256 * 256 + packet_cap * 2
                          + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
     return shared + (size_t)(calls_in_flight == 3 ? 3 : 2) * per_set;
@@ -1672,10 +1711,31 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
         HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, s));
     }
     HIPCHK(hipEventRecord(q.ev_front, s));
-    // back: cdf, chain, packets.  One call's back runs at a time (its scratch exists once).
+    // back: cdf and chain window by window, then the packets.  One call's back runs at a time (its
+    // scratch exists once).  cdf of window i+1 (its own stream) beside the chain of window i; a record
+    // buffer is refilled once the chain of two windows ago has read it.
     HIPCHK(hipStreamWaitEvent(lc.back, q.ev_front, 0));
+    HIPCHK(hipStreamWaitEvent(lc.cdfs, q.ev_front, 0));
+    if (lc.backdone_valid) HIPCHK(hipStreamWaitEvent(lc.cdfs, lc.ev_backdone, 0));
     HIPCHK(hipEventRecord(q.ev_back0, lc.back));
-    HIPCHK(ffv2_launch_lc_back(a, nframes, lc.back, q.ev_chain0, q.ev_chain1));
+    {
+        int i = 0;
+        for (uint32_t w0 = 0; w0 < lc.maxsym16; w0 += lc.window, i++) {
+            const uint32_t w1 = lc.maxsym16 - w0 < lc.window ? lc.maxsym16 : w0 + lc.window;
+            const int buf = i & 1;
+            if (i >= 2) HIPCHK(hipStreamWaitEvent(lc.cdfs, lc.ev_chain[buf], 0));
+            HIPCHK(ffv2_launch_lc_cdf(a, nframes, w0, w1, buf, lc.cdfs));
+            HIPCHK(hipEventRecord(lc.ev_cdf[buf], lc.cdfs));
+            HIPCHK(hipStreamWaitEvent(lc.back, lc.ev_cdf[buf], 0));
+            if (i == 0) HIPCHK(hipEventRecord(q.ev_chain0, lc.back));
+            HIPCHK(ffv2_launch_lc_chain(a, nframes, w0, w1, buf, lc.back));
+            HIPCHK(hipEventRecord(lc.ev_chain[buf], lc.back));
+        }
+    }
+    HIPCHK(hipEventRecord(q.ev_chain1, lc.back));
+    HIPCHK(ffv2_launch_lc_finish(a, nframes, lc.back));
+    HIPCHK(hipEventRecord(lc.ev_backdone, lc.back));
+    lc.backdone_valid = true;
     HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
     HIPCHK(hipMemcpyAsync(q.h_offs, q.offs, sizeof(unsigned long long) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, lc.back));

@@ -106,7 +106,7 @@ hipError_t ffv2_launch_rangecoder(const FFV2RangeCoderArgs &a, int nframes, hipS
 // qp > 0 entropy coder with many frames in flight (ffv2_lanecoder.hip): the serial range chain
 // runs one frame per lane, everything else is data parallel.  Frames in flight are numbered
 // 0..F-1; `width` of them share a wavefront of the chain kernel.
-struct FFV2LaneState { uint32_t woff, o, rng, full; };   // where the next symbol would land (word, bit), the range, words exhausted
+struct FFV2LaneState { uint32_t woff, o, rng, full, acc, pad0, pad1, pad2; };   // where the next symbol would land (word, bit), the range, words exhausted, the word so far
 struct FFV2LaneCoderArgs {
     int nblk, planes, qp, width, f0;
     const uint32_t *codes;            // [F][nblk][16] T-stage records
@@ -120,8 +120,13 @@ struct FFV2LaneCoderArgs {
     uint32_t *delta;                  // [F][13][nblk] coding-order index minus row index of a band's first symbol
     uint8_t *rows;                    // [F][row_stride] |pulse| per CDF row, rows back to back
     size_t row_stride;
-    uint2 *recs;                      // coding-order records {fl | fh << 16, ft}, interleaved (lc_record)
-    size_t group_stride;              // uint2 per group of `width` frames
+    uint2 *recs;                      // coding-order records {fl | fh << 16, ft} of ONE WINDOW of the coding order, interleaved
+                                      // (lc_record); two buffers, buf_stride uint2 apart (cdf of window i+1 beside the chain of window i)
+    size_t group_stride;              // uint2 per group of `width` frames (window symbols x width)
+    size_t buf_stride;
+    uint32_t win0, win1;              // this launch's window: symbols [win0, win1) of every frame's coding order
+    int win_buf;                      // which record buffer
+    uint32_t *cdfstate;               // [F][13][68] a CDF row between windows: 64 entries, total, position, block-plane
     const uint2 *split;               // [superblocks] the data-independent "no split" symbols (ffv2enc.c:222)
     uint2 header;                     // ff_daalaent_encode_uint(pix_fmt, 196)'s range-coded part (ffv2enc.c:449)
     uint32_t header_bits, header_nbits; // raw: pix_fmt & 15, Exp-Golomb(qp)
@@ -138,8 +143,10 @@ struct FFV2LaneCoderArgs {
     uint4 *fin;                       // [F] range bytes, slack bits, bytes the carry chain covers
 };
 hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
-hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s,                      // cdf, chain, finish of frames 0..nframes-1;
-                               hipEvent_t chain_begin, hipEvent_t chain_end);                             // optional timing events around the chain kernel
+// the back of frames 0..nframes-1, window by window (symbols [w0, w1) of every frame, record buffer buf), then finish
+hipError_t ffv2_launch_lc_cdf(const FFV2LaneCoderArgs &a, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t s);
+hipError_t ffv2_launch_lc_chain(const FFV2LaneCoderArgs &a, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t s);
+hipError_t ffv2_launch_lc_finish(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s);
 
 // The T-stage of ONE frame in plain wrapping int32 (ffv2_wide.hip): any 16-bit sample, any gain.
 // plane: int32 [planes][64 nsy][64 nsx] workspace; coef optional [nblk][4096]; energy [nblk][13]

@@ -22,6 +22,16 @@
 //            the code is sum_k u_k << (T - D_k) (D_k = shifts before symbol k), accumulated into
 //            32-bit words anchored every 16 bits of depth; a symbol shifts by <= 15 bits, so the
 //            anchor advances by 0 or 1 per symbol.
+//   windows  (round 3) cdf and chain do not run once over whole frames but alternate over WINDOWS of the
+//            coding order -- symbols [w0, w1) of every frame, the same bounds for all frames -- so the
+//            records exist only for two windows at a time (8 bytes x window x 2 per frame instead of
+//            8 bytes per coefficient: 50 MB per 1080p frame before).  Both kernels keep their state
+//            between windows in HBM: a CDF row as it stands (64 entries, total, position: 272 bytes
+//            per row and frame), a frame's range, word position and current word.  A row's chunk of 64
+//            symbols that straddles w1 is cut there -- chunk lengths are a pure function of (total,
+//            position), so the next window resumes with the chunk the uncut run would have had next
+//            only if nothing was cut; cutting never changes a symbol's (fl, fh, ft): they depend on
+//            the symbols before it alone.  cdf of window i+1 runs beside the chain of window i.
 //   finish   per frame: ff_daalaent_encode_done's rounding (:624-674) as one more addend (size),
 //            a prefix sum over the packet sizes (offsets: the packets leave the device packed),
 //            the words to bytes through a one-bit carry look-ahead (:706-715) and the raw bytes
@@ -31,6 +41,8 @@
 #include "ffv2_kernels.h"
 
 namespace {
+
+#define LC_CDF_STATE 68                     // dwords a CDF row keeps between windows: 64 entries, total, position, block-plane, pad
 
 __constant__ int LC_BS[FFV2_NUM_BANDS + 1] = { 0, 15, 23, 31, 63, 95, 127, 255, 383, 511, 1023, 1535, 2047, 4096 };
 
@@ -228,17 +240,27 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     uint32_t R = (uint32_t)lane + 1u;            // lane i: entry i of the row (daalaent_cdf_alloc(13, qp, 64, 0, 6, 0))
     uint32_t F0 = (uint32_t)n;                   // entry n-1: advances with the symbol count alone
     uint32_t k0 = 0, bp_cur = 0;
-    uint32_t seg_end = rowbase[1], dl_cur = delta[0];      // end of the current block-plane's band in this row, its delta
-    uint2 *recs = lc_record(a.recs, a.group_stride, a.width, f, 0);   // this frame's slot 0 of piece 0
-    auto put = [&](uint32_t gp, uint2 r) { recs[((size_t)(gp >> 3) * (size_t)a.width) * 8 + (gp & 7u)] = r; };
+    // this window's records: symbol gp of the frame goes to slot gp - w0 of its lane
+    uint2 *recs = lc_record(a.recs + (size_t)a.win_buf * a.buf_stride, a.group_stride, a.width, f, 0);
+    const uint32_t w0 = a.win0, w1 = a.win1;
+    auto put = [&](uint32_t gp, uint2 r) {
+        const uint32_t k = gp - w0;
+        recs[((size_t)(k >> 3) * (size_t)a.width) * 8 + (k & 7u)] = r;
+    };
+    auto inwin = [&](uint32_t gp) { return gp >= w0 && gp < w1; };
+    // the row as the previous window left it: entries, total, position, block-plane
+    uint32_t *st = a.cdfstate + ((size_t)f * 13 + b) * LC_CDF_STATE;
     if (b == 0) {
         // the symbols that carry no data: header, one "no split" per superblock (in front of its first
         // plane's symbols), the padding of the last tile with symbols of probability one
         const uint32_t *gbase = a.gbase + (size_t)f * (nb + 1);
-        if (lane == 0) put(0, a.header);
-        for (int sb = lane; sb * a.planes < nb; sb += 64) put(gbase[sb * a.planes] - 1u, a.split[sb]);
+        if (lane == 0 && w0 == 0) put(0, a.header);
+        for (int sb = lane; sb * a.planes < nb; sb += 64) {
+            const uint32_t gp = gbase[sb * a.planes] - 1u;
+            if (inwin(gp)) put(gp, a.split[sb]);
+        }
         const uint32_t nsym = gbase[nb], k = nsym + (uint32_t)lane;
-        if (lane < 16 && k < ((nsym + 15u) & ~15u)) put(k, make_uint2(0x80000000u, 0x8000u));   // fl 0, fh = ft = 32768
+        if (lane < 16 && k < ((nsym + 15u) & ~15u) && inwin(k)) put(k, make_uint2(0x80000000u, 0x8000u));   // fl 0, fh = ft = 32768
     }
     auto chunk_len = [&](uint32_t F, uint32_t k, bool *halve) {
         // symbols until (and including) the one whose update halves the row (daala_entropy.c:434)
@@ -247,20 +269,59 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         *halve = th + 1u <= m;
         return *halve ? th + 1u : m;
     };
+    if (w0 != 0) {                               // not the first window: resume
+        k0 = st[65];
+        if (k0 >= L) return;                     // the row is through
+        R = st[lane]; F0 = st[64]; bp_cur = st[66];
+    }
+    uint32_t seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;     // end of the current block-plane's band in this row
+    uint32_t dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;                      // ... and its delta
     bool halve = false;
     uint32_t m = k0 < L ? chunk_len(F0, k0, &halve) : 0u;
     // symbols are loaded unconditionally (address clamped to the row) and masked when used: a
     // load under a lane mask makes the compiler wait for it on the spot
     const uint32_t last = L ? L - 1u : 0u;
-    uint32_t xr = src[(uint32_t)lane < last ? (uint32_t)lane : last];
+    const uint32_t p0 = k0 + (uint32_t)lane;
+    uint32_t xr = src[p0 < last ? p0 : last];
     while (k0 < L) {
         // the next chunk's symbols are on their way while this one is worked on
-        const uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
-        const uint32_t k1 = k0 + m;
+        uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
+        uint32_t k1 = k0 + m;
         bool halve1 = false;
         const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
         const uint32_t p1 = k1 + (uint32_t)lane;
         const uint32_t xr1 = src[p1 < last ? p1 : last];
+
+        // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
+        // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
+        // prefix count over them gives every lane its block-plane.
+        uint32_t dl, rel = 0xFFFFFFFFu;
+        const bool inside = seg_end - k0 >= m && seg_end - k0 > 0u;
+        if (inside) {
+            dl = dl_cur;
+        } else {
+            const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
+            const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
+            rel = idx <= (uint32_t)nb ? rb - k0 : 0xFFFFFFFFu;         // > 0: bp_cur holds symbol k0
+            flag[lane] = 0;
+            if (lane < 2) flag[64 + lane] = 0;
+            __syncthreads();
+            if (rel <= 64u) flag[rel] = 1;
+            __syncthreads();
+            const uint32_t mine = flag[lane];
+            const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
+            dl = delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
+        }
+        // the window ends inside this chunk (coding-order positions grow with the lane): cut it there
+        const uint32_t gp = k0 + (uint32_t)lane + dl;
+        const unsigned long long over = __ballot((uint32_t)lane < m && gp >= w1);
+        bool last_chunk = false;
+        if (over) {
+            const uint32_t mc = (uint32_t)__ffsll((long long)over) - 1u;
+            if (mc == 0u) break;                                       // nothing of this chunk belongs to the window
+            m = mc; halve = false; last_chunk = true;
+            F1 = F0 + 64u * m; k1 = k0 + m;
+        }
         const uint32_t x = (uint32_t)lane < m ? xr : 255u;
 
         // prefix counts: cl / ch = symbols of this chunk in front of lane t with a value below / up
@@ -283,37 +344,21 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         const int sc = __clz(ft - 1u) - 17;                          // 15 - ilog(ft - 1), daala_entropy.c:346
         fl <<= sc; fh <<= sc; ft <<= sc;
 
-        // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
-        // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
-        // prefix count over them gives every lane its block-plane.
-        uint32_t dl;
-        if (seg_end - k0 >= m && seg_end - k0 > 0u) {
-            dl = dl_cur;
+        // the block-plane the row stands in after this chunk
+        if (inside) {
             if (seg_end - k0 == m) {                                   // the band ends with this chunk
                 bp_cur++;
                 seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
                 dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
             }
         } else {
-            const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
-            const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
-            const uint32_t rel = rb - k0;                              // > 0: bp_cur holds symbol k0
-            flag[lane] = 0;
-            if (lane < 2) flag[64 + lane] = 0;
-            __syncthreads();
-            if (idx <= (uint32_t)nb && rel <= 64u) flag[rel] = 1;
-            __syncthreads();
-            const uint32_t mine = flag[lane];
-            const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
-            dl = delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
-            bp_cur += (uint32_t)__popcll(__ballot(idx <= (uint32_t)nb && rel <= m));
+            bp_cur += (uint32_t)__popcll(__ballot(rel <= m));
             seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
             dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
         }
         if ((uint32_t)lane < m) {
             if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
             else {
-                const uint32_t gp = k0 + (uint32_t)lane + dl;
 #if defined(LC_CDF_EXP) && LC_CDF_EXP == 1    // timing experiment: no record stores
                 if (gp == 0xFFFFFFFFu) put(gp, make_uint2(fl | (fh << 16), ft));
 #else
@@ -327,8 +372,13 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         const uint32_t ge = lastx <= (uint32_t)lane ? 1u : 0u;
         if (halve) R = ((R + 64u * (ca - ge)) >> 1) + (uint32_t)lane + 1u + 64u * ge;
         else R += 64u * ca;
-        F0 = F1; k0 = k1; m = m1; halve = halve1; xr = xr1;
+        F0 = F1; k0 = k1;
+        if (last_chunk) break;
+        m = m1; halve = halve1; xr = xr1;
     }
+    // the row as it stands, for the next window
+    st[lane] = R;
+    if (lane == 0) { st[64] = F0; st[65] = k0; st[66] = bp_cur; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -402,12 +452,16 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
     const int g = blockIdx.x, lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int f = g * a.width + lane;
     const bool live = lane < a.width && f < nframes;
+    // this window: tiles [t0, t1) of every frame's coding order (a tile = 16 symbols)
+    const uint32_t t0 = a.win0 >> 4, t1 = a.win1 >> 4;
     uint32_t nsym = 0;
     if (live && a.abort_[f] == 0 && a.status_in[f] >= 0) nsym = a.gbase[(size_t)f * (a.nblk + 1) + a.nblk];
-    const uint32_t ntiles = (nsym + 15u) >> 4;
+    const uint32_t alltiles = (nsym + 15u) >> 4;
+    const uint32_t ntiles = alltiles > t0 ? (alltiles < t1 ? alltiles : t1) - t0 : 0u;   // of this frame, in this window
     uint32_t maxt = ntiles;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)maxt, o, 64); maxt = t > maxt ? t : maxt; }
+    if (maxt == 0) return;                                             // no frame of this group reaches into the window
     if (threadIdx.x == 0) { produced = 0; consumed = 0; }
     __syncthreads();
     // the two tile counters: relaxed workgroup-scope LDS accesses, ordered against the ring by hand
@@ -420,13 +474,17 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
     };
     uint32_t *words = a.words + (size_t)(live ? f : 0) * a.wcap;
     const uint32_t wlimit = a.wcap - 2u;                               // a frame that runs past its words is refused by lc_finish_kernel
-    LcWords s{ 1u, 0u, 0u };
+    // where the previous window left the frame: the range (producer), the word position and the word so far (consumer)
+    FFV2LaneState st0{ 0u, 1u, 0x8000u, 0u, 0u, 0u, 0u, 0u };
+    if (t0 != 0 && live) st0 = a.state[f];
+    LcWords s{ st0.o, st0.acc, st0.woff };
 
     if (role == 0) {
         // ---- the recurrence ----
-        const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)g * a.group_stride) + (size_t)(live ? lane : 0) * 4;
+        const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)a.win_buf * a.buf_stride + (size_t)g * a.group_stride)
+                            + (size_t)(live ? lane : 0) * 4;
         const size_t piece = (size_t)a.width * 4;                      // uint4 per piece row (64 bytes per lane)
-        uint32_t rng = 0x8000u;
+        uint32_t rng = st0.rng;
         // records two tiles ahead of the one being worked on (a tile is ~2 500 cycles of recurrence)
         uint4 buf[3][8];
 #pragma unroll
@@ -478,11 +536,12 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
     }
     __syncthreads();                                                   // final_rng
     if (role == 1 && live) {
-        // the word the next symbol would go to, and a clear one behind it
+        // the word the next symbol would go to, and a clear one behind it (the next window carries on from here)
         words[s.woff] = s.acc;
         words[s.woff + 1] = 0;
         FFV2LaneState st;
-        st.woff = s.woff; st.o = s.o; st.rng = final_rng[lane]; st.full = s.woff >= wlimit ? 1u : 0u;
+        st.woff = s.woff; st.o = s.o; st.rng = final_rng[lane]; st.full = (st0.full || s.woff >= wlimit) ? 1u : 0u;
+        st.acc = s.acc; st.pad0 = st.pad1 = st.pad2 = 0u;
         a.state[f] = st;
     }
 }
@@ -616,12 +675,26 @@ hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, in
     return hipGetLastError();
 }
 
-hipError_t ffv2_launch_lc_back(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s, hipEvent_t chain_begin, hipEvent_t chain_end)
+// cdf and chain of one window of the coding order: symbols [w0, w1) of every frame (w0, w1 multiples of
+// 16), records in buffer `buf` (0 | 1).  cdf on stream `sc`, chain on `sk`; the caller orders them.
+hipError_t ffv2_launch_lc_cdf(const FFV2LaneCoderArgs &a0, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t sc)
 {
-    hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, s, a);
-    if (chain_begin) (void)hipEventRecord(chain_begin, s);
-    hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(128), 0, s, a, nframes);
-    if (chain_end) (void)hipEventRecord(chain_end, s);
+    FFV2LaneCoderArgs a = a0;
+    a.win0 = w0; a.win1 = w1; a.win_buf = buf;
+    hipLaunchKernelGGL(lc_cdf_kernel, dim3(13, (unsigned)nframes), dim3(64), 0, sc, a);
+    return hipGetLastError();
+}
+
+hipError_t ffv2_launch_lc_chain(const FFV2LaneCoderArgs &a0, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t sk)
+{
+    FFV2LaneCoderArgs a = a0;
+    a.win0 = w0; a.win1 = w1; a.win_buf = buf;
+    hipLaunchKernelGGL(lc_chain_kernel, dim3((unsigned)((nframes + a.width - 1) / a.width)), dim3(128), 0, sk, a, nframes);
+    return hipGetLastError();
+}
+
+hipError_t ffv2_launch_lc_finish(const FFV2LaneCoderArgs &a, int nframes, hipStream_t s)
+{
     hipLaunchKernelGGL(lc_size_kernel, dim3((unsigned)nframes), dim3(64), 0, s, a);
     hipLaunchKernelGGL(lc_offsets_kernel, dim3(1), dim3(256), 0, s, a, nframes);
     hipLaunchKernelGGL(lc_write_kernel, dim3((unsigned)nframes), dim3(256), 0, s, a);

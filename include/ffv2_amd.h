@@ -187,8 +187,9 @@ int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
  * carry propagation) data-parallel.  Throughput grows with the frames in flight until the other
  * kernels bound it; a call takes at least one frame's chain (about 73 ns per symbol).
  *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call
- *                      (ffv2amd_lanecoder_bytes_per_frame() each: 84 MB per 1080p frame with the
- *                      default packet_cap and two calls in flight);
+ *                      (ffv2amd_lanecoder_bytes_per_frame() each: 38 MB per 1080p frame with the
+ *                      default packet_cap and two calls in flight; round 2: 84 MB, before the range
+ *                      chain's input was produced window by window);
  *                      FFV2AMD_ERR_NOMEM if the device cannot hold it.  packet_cap = 0 reserves
  *                      ffv2amd_info.packet_cap_qp bytes per packet (2 100 per block-plane, six
  *                      buffers of that size per frame); a smaller packet_cap saves HBM, and a frame
@@ -222,6 +223,9 @@ int    ffv2amd_lanecoder_finish_packed(ffv2amd_encoder *enc, uint8_t *h_buf, siz
 /* Timing of the call finished last: its range-chain kernel and its whole back (cdf, chain, packets), in ms on
  * the device clock, and the symbols the coder read for the call's first frame.  For benchmarks. */
 int    ffv2amd_lanecoder_stats(const ffv2amd_encoder *enc, float *chain_ms, float *back_ms, uint32_t *symbols_frame0);
+/* Test hook (process-wide, read by the next lanecoder_open): symbols of the coding order the back works on at a
+ * time (0 = the default, 2^18; the environment variable FFV2AMD_LC_WINDOW sets the same at start-up). */
+void   ffv2amd_debug_lanecoder_window(uint32_t symbols);
 int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp,
                                 const int32_t *d_W, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

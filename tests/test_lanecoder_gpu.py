@@ -242,3 +242,43 @@ def test_lanecoder_open_beyond_hbm_is_refused_cleanly(oracle):
     pk, sizes, status = enc.lanecoder_encode(enc.upload(frame), 16, as_arrays=True)
     assert status[0] == 0 and pk[0, : sizes[0]].tobytes() == oracle.encode(frame[0], "yuv444p", qp=16)
     enc.close()
+
+
+@pytest.mark.parametrize("window", [16, 48, 1008, 5000, 0])
+@pytest.mark.parametrize("fmt,P,H,W,depth,qp", [("yuv444p", 3, 100, 150, 8, 16), ("gray", 1, 130, 70, 8, 5), ("yuv444p10le", 3, 64, 200, 10, 40)])
+def test_lanecoder_windows_of_the_coding_order(oracle, window, fmt, P, H, W, depth, qp):
+    """Round 3: cdf and chain alternate over windows of the coding order (records exist for two windows only).
+    Whatever the window -- 16 symbols cut every chunk of a CDF row, 48 cut it at changing places, 0 is the
+    default of 2^18 -- the packets are the host coder's and the oracle's; frames of uneven length (a quiet
+    half, a structured frame that aborts) share the group of lanes."""
+    from ffmpeg_ffv2_amd import _lib
+    lib = _lib.load()
+    lib.ffv2amd_debug_lanecoder_window(window)
+    try:
+        enc = _enc(W, H, fmt, 2)
+        n = 5
+        frames = np.stack([synth.noise(31 * qp + i, P, H, W, depth) for i in range(n)])
+        frames[1, :, H // 2:, :] = (1 << (depth - 1)) + frames[1, :, H // 2:, :] % 3          # much less to code
+        frames[3] = synth.make("S1", 3, P, H, W, depth)                                          # usually aborts
+        dev = enc.upload(frames)
+        enc.lanecoder_open(n)
+        for rep in range(2):                                  # the second call finds the first one's state in the scratch
+            pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+            for i in range(n):
+                try:
+                    want = oracle.encode(frames[i], fmt, qp=qp)
+                except Exception:
+                    want = None
+                if want is None:
+                    assert status[i] == -1, (rep, i, status[i])
+                else:
+                    assert status[i] == 0 and pk[i, : sizes[i]].tobytes() == want, (rep, i, window)
+        # two calls in flight: the second call's windows wait for the first call's back
+        assert enc.lanecoder_submit(dev[:3], qp) and enc.lanecoder_submit(dev[2:], qp)
+        pk_a, sz_a, _ = enc.lanecoder_finish()
+        first = pk_a[2, : sz_a[2]].tobytes()               # the page-locked array is reused by the next finish of this shape
+        pk_b, sz_b, _ = enc.lanecoder_finish()
+        assert first == pk_b[0, : sz_b[0]].tobytes() == oracle.encode(frames[2], fmt, qp=qp)
+        enc.close()
+    finally:
+        lib.ffv2amd_debug_lanecoder_window(0)

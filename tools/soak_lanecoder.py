@@ -20,10 +20,13 @@ if ROOT not in sys.path:
 FMTS = [("gray", 1, 8), ("yuv444p", 3, 8), ("yuv444p10le", 3, 10), ("gbrp12le", 3, 12), ("yuv444p12le", 3, 12), ("gbrp", 3, 8)]
 
 
-def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False):
-    """Returns (frames identical, aborts agreed, packet bytes compared)."""
-    from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth
+def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False, windows=(0, 0, 16, 48, 400, 4096, 65536)):
+    """Returns (frames identical, aborts agreed, packet bytes compared).  windows: the coder's window sizes
+    (symbols of the coding order cdf and chain work on at a time; 0 = default) drawn per case -- tiny ones cut
+    the rows' chunks of 64 symbols at every possible place."""
+    from ffmpeg_ffv2_amd import FFV2Encoder, frames as synth, _lib
     from ffmpeg_ffv2_amd._lib import FFV2Error
+    lib = _lib.load()
     rnd = random.Random(seed)
     checked = aborted = nbytes = 0
     t0 = time.time()
@@ -47,6 +50,7 @@ def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False):
             frames.append(f)
         frames = np.stack(frames)
         dev = enc.upload(frames)
+        lib.ffv2amd_debug_lanecoder_window(rnd.choice(windows))
         enc.lanecoder_open(n, rnd.choice([0, 0, 4096 + enc.info.block_planes * 600]))
         pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
         for i in range(n):
@@ -63,6 +67,7 @@ def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False):
             checked += 1
             nbytes += len(want)
         enc.close()
+        lib.ffv2amd_debug_lanecoder_window(0)
         if it % 25 == 24 and not quiet:
             print("%d cases, %d frames identical, %d aborts agreed, %.0f s" % (it + 1, checked, aborted, time.time() - t0), flush=True)
     return checked, aborted, nbytes

@@ -192,6 +192,31 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                                  ("the range recurrence, one frame per lane: its time does not depend on the frames in flight; "
                                   "bound by the issue rate of a lone wavefront, not by HBM or MFMA (last step's values)",))),
                "roofline": None}
+        # the Q-stage kernel alone (the largest part of a call's front once the range chain is amortised over
+        # thousands of frames): every element of a band is re-scored for every pulse, as the asm does
+        # (celt_pvq_search.asm:85-191), one IEEE f32 division each.  Neither HBM nor MFMA bounds it; it is held
+        # against the rate at which the chip can issue the 11-instruction division sequence.
+        try:
+            import ctypes as C
+            from ffmpeg_ffv2_amd import _lib as L
+            ms = C.c_float(0)
+            nq = min(16, F)
+            L.check(L.load().ffv2amd_debug_pvq_time(enc._h, nq, d_frames.data_ptr(), args.qp, 10, C.byref(ms)), "pvq_time")
+            bands = [15, 8, 8, 32, 32, 32, 128, 128, 128, 512, 512, 512, 2049]
+            # pulses left to the greedy loop: on flat spectra the projection rounds every pulse away, all qp are searched
+            div_per_bp = sum(((n + 3) // 4 * 4) * args.qp for n in bands)
+            divs = div_per_bp * enc.info.block_planes * nq
+            rate = divs / (ms.value * 1e-3)
+            peak = 256 * 4 * 16 * 2.4e9 / 11            # CUs x SIMDs x lanes x clock / instructions of the division sequence
+            res["roofline"] = {"bound": "valu (IEEE f32 division, 11 instructions)", "kernel": "ffv2_pvq_kernel",
+                               "achieved": round(rate / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T divisions/s",
+                               "frac": round(rate / peak, 3), "traffic": None,
+                               "kernel_ms_avg": round(ms.value, 4), "frames_per_launch": nq,
+                               "divisions_per_block_plane": div_per_bp,
+                               "what": "ffv2_pvq_kernel alone, %d frames per launch, 10 launches; divisions = elements x pulses "
+                                       "(upper bound: every pulse searched); peak = f32 VALU lanes x 2.4 GHz / 11" % nq}
+        except Exception as ex:
+            res["roofline"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
             oracle = oracle_lib.load()
@@ -279,6 +304,8 @@ def main():
     if args.warmup is None:
         args.warmup = 1 if lane_mode else 50
 
+    # before the HIP runtime initialises (and inherited by the ranks started below): see ffmpeg_ffv2_amd/_lib.py
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -336,7 +363,7 @@ def main():
             if not args.packet_cap:
                 args.packet_cap = 4096 + 700 * enc.info.block_planes      # noise at qp 16 / 64 codes to 160 / 370 B per block-plane
             per = enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight)
-            args.frames_in_flight = max(64, min(2048, int(160e9 // per) // 64 * 64))
+            args.frames_in_flight = max(64, min(8192, int(160e9 // per) // 64 * 64))
         lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
         return
     if args.qp > 0:
@@ -535,6 +562,7 @@ def main():
                 y4["pinned_fraction_of_h2d_copy_rate"] = round(y4["pinned"]["h2d_GBs_per_gpu"] / rate, 3)
                 hb["yuv420"] = y4
                 hb420_first = (pk420[0], yuv420_of(host_frames[0]))
+            hb["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
             hb["frames_per_gpu"] = nf
             hb["ring_depth"] = args.ring_depth
             hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "

@@ -854,6 +854,12 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     if (pixfmt_info(pix_fmt, &planes, &depth) < 0) return FFV2AMD_ERR_INVAL;
     if (width < 1 || height < 1 || width > 65536 || height > 65536 || max_batch < 1) return FFV2AMD_ERR_INVAL;
 
+    // The ring runs five HIP streams side by side and the lane coder four; the runtime multiplexes streams
+    // onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue wait for each
+    // other's kernels (measured, round 3: pageable 4:2:0 frames through the ring 12.1 -> 16.1 Gpix/s, the
+    // lane coder 5.7 -> 7.0 Gpix/s with 8 queues).  The variable is read when the runtime initialises, so
+    // this only helps a process whose first HIP call is ours; others set it themselves.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         fprintf(stderr, "ffv2amd: no usable HIP device %d (found %d) -- this library has no CPU path\n", device, ndev);
@@ -1621,6 +1627,39 @@ int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t pack
 
 void ffv2amd_debug_lanecoder_window(uint32_t symbols) { g_lc_window = symbols; }
 
+// Benchmark aid: the Q-stage kernel alone.  T-stage of `nframes` (<= max_batch) device-resident frames once,
+// then `reps` launches of ffv2_pvq_kernel over their coefficients between two events -> ms per launch.
+int ffv2amd_debug_pvq_time(ffv2amd_encoder *e, int nframes, const void *d_frames, int qp, int reps, float *ms_per_launch)
+{
+    if (!e || !d_frames || !ms_per_launch || nframes < 1 || nframes > e->info.max_batch || qp < 1 || reps < 1) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const size_t nb = (size_t)e->info.block_planes, B = (size_t)e->info.max_batch;
+    if (!e->d_coef_ws) {
+        HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
+        HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
+    }
+    hipStream_t s = e->stream;
+    FFV2TStageArgs t{};
+    t.g = e->geom; t.nframes = nframes; t.frames = (const uint8_t *)d_frames;
+    t.coef = e->d_coef_ws; t.codes = e->d_codes; t.bitcnt = e->d_bitoff;
+    t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = e->d_status;
+    HIPCHK(hipMemsetAsync(e->d_status, 0, sizeof(int32_t) * nframes, s));
+    HIPCHK(ffv2_launch_tstage(t, s));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    HIPCHK(ffv2_launch_pvq(e->d_coef_ws, nullptr, e->d_y, qp, (long long)nb * nframes, s));      // warm
+    HIPCHK(hipEventRecord(a, s));
+    for (int r = 0; r < reps; r++) HIPCHK(ffv2_launch_pvq(e->d_coef_ws, nullptr, e->d_y, qp, (long long)nb * nframes, s));
+    HIPCHK(hipEventRecord(b, s));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / reps;
+    return FFV2AMD_OK;
+}
+
 int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
@@ -1714,22 +1753,29 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     // back: cdf and chain window by window, then the packets.  One call's back runs at a time (its
     // scratch exists once).  cdf of window i+1 (its own stream) beside the chain of window i; a record
     // buffer is refilled once the chain of two windows ago has read it.
+    // (FFV2AMD_LC_SERIAL=1: everything on the back stream, cdf and chain of a window one after the other)
+    static const bool serial = getenv("FFV2AMD_LC_SERIAL") && atoi(getenv("FFV2AMD_LC_SERIAL")) != 0;
+    hipStream_t sc = serial ? lc.back : lc.cdfs;
     HIPCHK(hipStreamWaitEvent(lc.back, q.ev_front, 0));
-    HIPCHK(hipStreamWaitEvent(lc.cdfs, q.ev_front, 0));
-    if (lc.backdone_valid) HIPCHK(hipStreamWaitEvent(lc.cdfs, lc.ev_backdone, 0));
+    if (!serial) {
+        HIPCHK(hipStreamWaitEvent(sc, q.ev_front, 0));
+        if (lc.backdone_valid) HIPCHK(hipStreamWaitEvent(sc, lc.ev_backdone, 0));
+    }
     HIPCHK(hipEventRecord(q.ev_back0, lc.back));
     {
         int i = 0;
         for (uint32_t w0 = 0; w0 < lc.maxsym16; w0 += lc.window, i++) {
             const uint32_t w1 = lc.maxsym16 - w0 < lc.window ? lc.maxsym16 : w0 + lc.window;
-            const int buf = i & 1;
-            if (i >= 2) HIPCHK(hipStreamWaitEvent(lc.cdfs, lc.ev_chain[buf], 0));
-            HIPCHK(ffv2_launch_lc_cdf(a, nframes, w0, w1, buf, lc.cdfs));
-            HIPCHK(hipEventRecord(lc.ev_cdf[buf], lc.cdfs));
-            HIPCHK(hipStreamWaitEvent(lc.back, lc.ev_cdf[buf], 0));
+            const int buf = serial ? 0 : i & 1;
+            if (!serial && i >= 2) HIPCHK(hipStreamWaitEvent(sc, lc.ev_chain[buf], 0));
+            HIPCHK(ffv2_launch_lc_cdf(a, nframes, w0, w1, buf, sc));
+            if (!serial) {
+                HIPCHK(hipEventRecord(lc.ev_cdf[buf], sc));
+                HIPCHK(hipStreamWaitEvent(lc.back, lc.ev_cdf[buf], 0));
+            }
             if (i == 0) HIPCHK(hipEventRecord(q.ev_chain0, lc.back));
             HIPCHK(ffv2_launch_lc_chain(a, nframes, w0, w1, buf, lc.back));
-            HIPCHK(hipEventRecord(lc.ev_chain[buf], lc.back));
+            if (!serial) HIPCHK(hipEventRecord(lc.ev_chain[buf], lc.back));
         }
     }
     HIPCHK(hipEventRecord(q.ev_chain1, lc.back));

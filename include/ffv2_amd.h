@@ -226,6 +226,9 @@ int    ffv2amd_lanecoder_stats(const ffv2amd_encoder *enc, float *chain_ms, floa
 /* Test hook (process-wide, read by the next lanecoder_open): symbols of the coding order the back works on at a
  * time (0 = the default, 2^18; the environment variable FFV2AMD_LC_WINDOW sets the same at start-up). */
 void   ffv2amd_debug_lanecoder_window(uint32_t symbols);
+/* Benchmark aid: the Q-stage (PVQ search) kernel alone on `nframes` (<= max_batch) device-resident frames:
+ * average ms per launch over `reps` launches (bench.py --qp reports it against the f32 division rate). */
+int    ffv2amd_debug_pvq_time(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, int reps, float *ms_per_launch);
 int    ffv2amd_lanecoder_encode(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp,
                                 const int32_t *d_W, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

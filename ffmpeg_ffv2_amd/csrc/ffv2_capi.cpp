@@ -613,7 +613,7 @@ struct ffv2amd_encoder {
     int32_t *coef_sink = nullptr;
     int profiling = 0;                   // 0 off, n: HIP timing events around every n-th batch call
     unsigned prof_calls = 0;
-    struct EvTriple { hipEvent_t a, b, c, d; };     // T start, T end, E end, E start
+    struct EvTriple { hipEvent_t a, b, c, d; bool d_is_b; };     // T start, T end, E end, E start (== T end when both stages share a stream)
     // pipelined mode: the E-stage of call n runs on e_stream while the caller's stream
     // already carries the T-stage of call n+1; two sets of T->E hand-off buffers
     bool pipelined = false;
@@ -764,7 +764,8 @@ static int launch_encode_qp0(ffv2amd_encoder *e, int nframes, const void *d_fram
         HIPCHK(hipEventRecord(join, st));
         HIPCHK(hipStreamWaitEvent(se, join, 0));
     }
-    if (ev) HIPCHK(hipEventRecord(ev->d, se));
+    if (ev && se != st) HIPCHK(hipEventRecord(ev->d, se));       // one stream: the T-stage's end event is the E-stage's start
+    if (ev) ev->d_is_b = se == st;
     FFV2EStageArgs b{};
     b.g = e->geom; b.nframes = nframes; b.codes = codes; b.bitoff = bitcnt;
     b.packets = (uint8_t *)d_packets; b.packet_stride = packet_stride;
@@ -1086,7 +1087,7 @@ int ffv2amd_profile_read_ex(ffv2amd_encoder *e, double *tstage_ms, double *estag
         HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].a, e->ev_pool[i].b)); t += ms;
         if (n == 0 || ms < lo) lo = ms;
         if (n == 0 || ms > hi) hi = ms;
-        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].d, e->ev_pool[i].c)); x += ms;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i].d_is_b ? e->ev_pool[i].b : e->ev_pool[i].d, e->ev_pool[i].c)); x += ms;
         n++;
     }
     e->ev_used = 0;

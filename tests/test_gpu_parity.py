@@ -575,3 +575,30 @@ def test_walk_kernel_sample_out_of_range_and_full_frames(oracle, force_tstage):
     good = synth.make("S2", 1, 3, 128, 192, 10)
     assert enc.encode2(good) == oracle.encode(good, "yuv444p10le")      # the error flag does not stick
     enc.close()
+
+
+@pytest.mark.parametrize("N", [512, 700, 2049])
+@pytest.mark.parametrize("K", [2, 16, 40, 64, 200])
+def test_pvq_search_on_concentrated_and_tied_vectors(oracle, N, K):
+    """Large bands with energy on a few elements (they collect many pulses), exact ties in |x|, a dominant Sxy
+    (numerators absorb |x|), one class carrying everything, pulses placed by the projection: device search == oracle.
+    (Written for round 3's filtered greedy loop, which was bit-exact but slower and is not shipped; the vectors stay.)
+    Parity unpinned (qp > 0)."""
+    enc = _enc(64, 64, "gray")
+    rng = np.random.default_rng(77 * N + K)
+    X = rng.standard_normal((16, N)).astype(np.float32)
+    X[0, : N // 50] *= 40                                   # a few dominant elements: they collect the pulses
+    X[1] = np.sign(X[1]) * 0.5                              # all |x| equal: every pulse-free element is a candidate
+    X[2] = np.round(X[2] * 3) / 3                           # few distinct values
+    X[3, ::4] *= 30                                         # one class (i & 3 == 0) carries everything
+    X[4, 5] = 1000.0                                        # Sxy dwarfs every other |x| after the first pulse
+    X[5] = np.abs(rng.standard_normal(N)).astype(np.float32) * np.linspace(3, 0.01, N, dtype=np.float32)
+    X[6, N // 2:] = 0                                       # zeros (p = Sxy^2 / Syy ties among them)
+    X[7] = rng.laplace(size=N).astype(np.float32)
+    X[8, :70] *= 25                                         # more than 16 carriers per class once K is large
+    X /= np.linalg.norm(X, axis=1, keepdims=True) + 1e-9
+    got = enc.pvq_search(X, K)
+    for v in range(X.shape[0]):
+        want = oracle.pvq_search(X[v], K)
+        assert np.array_equal(got[v], want), "vector %d N=%d K=%d: first diff at %s" % (v, N, K, np.flatnonzero(got[v] != want)[:4])
+    enc.close()

@@ -55,10 +55,12 @@ def yuv420_of(frame):
     return [np.ascontiguousarray(frame[0]), np.ascontiguousarray(frame[1][::2, ::2]), np.ascontiguousarray(frame[2][::2, ::2])]
 
 
-def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pinned, barrier, yuv420=False):
+def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pinned, barrier, yuv420=False, register=False):
     """Host frames in, host packets out through the asynchronous ring (ffv2amd_ring_*): the
     metric as SURVEY.md 8(d) words it, PCIe included.  yuv420: the literal BASELINE pixel format
     (ffv2amd_ring_send_420: half the bytes over PCIe, chroma up-converted on the device).
+    register: pageable frames from a pool of long-lived buffers (what libavcodec's frame pools are), page-locked
+    by the ring the first time it sees each buffer (FFV2AMD_FRAME_REGISTER).
     Returns (seconds, packets, bytes per frame)."""
     enc = FFV2Encoder(W, H, fmt, device=local, max_batch=1)
     enc.ring_open(depth)
@@ -72,7 +74,7 @@ def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pi
                     d[:] = a
             src = pool
         frame_bytes = sum(a.shape[0] * a.shape[1] for a in src[0]) * enc.dtype.itemsize
-        send = lambda n: enc.ring_send_420(*src[n % nsrc], tag=n, pinned=pinned)
+        send = lambda n: enc.ring_send_420(*src[n % nsrc], tag=n, pinned=pinned, register=register)
     else:
         if pinned:
             src = enc.pinned_frames(nsrc)
@@ -80,7 +82,7 @@ def host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nframes, depth, pi
         else:
             src = host_frames
         frame_bytes = enc.info.planes * enc.info.width * enc.info.height * enc.dtype.itemsize
-        send = lambda n: enc.ring_send(src[n % nsrc], tag=n, pinned=pinned)
+        send = lambda n: enc.ring_send(src[n % nsrc], tag=n, pinned=pinned, register=register)
 
     def run(n):
         packets, sent = [], 0
@@ -515,10 +517,10 @@ def main():
             from ffmpeg_ffv2_amd import fanout
             nf = args.host_frames
             hb = {}
-            variants = [("pinned", True)] + ([("pageable", False)] if world == 1 else [])
+            variants = [("pinned", True)] + ([("pageable", False), ("pageable_registered", False)] if world == 1 else [])
             for name, pinned in variants:
                 dt, pk_local, frame_bytes = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
-                                                          pinned, barrier)
+                                                          pinned, barrier, register=name.endswith("registered"))
                 if world > 1:
                     tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -548,9 +550,9 @@ def main():
             # bicubic scale filter does, then the same T/E-stage.  Parity unpinned (no libswscale here).
             if fmt.startswith("yuv444p"):
                 y4 = {}
-                for name, pinned in [("pinned", True)] + ([("pageable", False)] if world == 1 else []):
+                for name, pinned in [("pinned", True)] + ([("pageable", False), ("pageable_registered", False)] if world == 1 else []):
                     dt, pk420, fb420 = host_boundary(FFV2Encoder, W, H, fmt, local, host_frames, nf, args.ring_depth,
-                                                     pinned, barrier, yuv420=True)
+                                                     pinned, barrier, yuv420=True, register=name.endswith("registered"))
                     if world > 1:
                         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -566,7 +568,10 @@ def main():
             hb["frames_per_gpu"] = nf
             hb["ring_depth"] = args.ring_depth
             hb["what"] = ("frames in host memory -> ffv2amd_ring_send/receive -> packets in host memory, "
-                          "H2D || T/E-stage || D2H on separate HIP streams; then in-order gather on rank 0")
+                          "H2D || T/E-stage || D2H on separate HIP streams; then in-order gather on rank 0.  pinned: "
+                          "page-locked frames (ffv2amd_host_alloc); pageable: ordinary memory, gathered by the ring's "
+                          "thread pool; pageable_registered: ordinary memory from a pool of %d buffers, page-locked by "
+                          "the ring on first sight (FFV2AMD_FRAME_REGISTER; the warm-up pass pays for it)" % host_frames.shape[0])
 
 
         except Exception as ex:          # never lose the headline line to the secondary phase

@@ -685,6 +685,9 @@ struct ffv2amd_encoder {
     hipStream_t ring_h2d = nullptr, ring_comp[2] = { nullptr, nullptr }, ring_d2h = nullptr, ring_pkt = nullptr;
     GatherPool *ring_pool = nullptr;
     unsigned ring_seq = 0;
+    // FFV2AMD_FRAME_REGISTER: host ranges this ring page-locked itself (frames from a pool of long-lived buffers)
+    struct RegRange { const uint8_t *base; size_t bytes; };
+    std::vector<RegRange> ring_reg;
     // qp > 0 coder with many frames in flight (ffv2amd_lanecoder_*, ffv2_lanecoder.hip)
     struct LaneCoder {
         int cap = 0;                     // frames in flight per call
@@ -2203,6 +2206,8 @@ void ffv2amd_ring_close(ffv2amd_encoder *e)
         if (r.ev_meta) (void)hipEventDestroy(r.ev_meta);
     }
     e->ring.clear();
+    for (auto &g : e->ring_reg) (void)hipHostUnregister((void *)g.base);
+    e->ring_reg.clear();
     if (e->ring_pool) { e->ring_pool->shutdown(); delete e->ring_pool; e->ring_pool = nullptr; }
     for (hipStream_t *st : { &e->ring_h2d, &e->ring_comp[0], &e->ring_comp[1], &e->ring_d2h, &e->ring_pkt })
         if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
@@ -2274,21 +2279,41 @@ static int ring_submit(ffv2amd_encoder *e, ffv2amd_encoder::RingSlot &r, const R
 {
     const ffv2amd_info &in = e->info;
     hipStream_t sh = e->ring_h2d;
-    if (flags & FFV2AMD_FRAME_PINNED) {
-        // page-locked planes: the DMA engine reads the caller's rows directly
-        for (int i = 0; i < npl; i++) {
-            const RingPlane &q = pl[i];
-            if (q.linesize == (ptrdiff_t)q.pitch)
-                HIPCHK(hipMemcpyAsync(q.d_dst, q.src, q.pitch * (size_t)(q.rows - 1) + q.row_bytes, hipMemcpyHostToDevice, sh));
-            else
-                HIPCHK(hipMemcpy2DAsync(q.d_dst, q.pitch, q.src, (size_t)q.linesize, q.row_bytes, (size_t)q.rows,
-                                        hipMemcpyHostToDevice, sh));
+    // Which planes the DMA engine may read in place: all of them when the caller says they are page-locked; with
+    // FFV2AMD_FRAME_REGISTER those whose memory this ring has page-locked itself -- on first sight of a buffer
+    // (hipHostRegister: milliseconds, once per buffer of the caller's pool), from the cache afterwards.
+    bool direct[4] = { false, false, false, false };
+    for (int i = 0; i < npl; i++) {
+        const RingPlane &q = pl[i];
+        if (flags & FFV2AMD_FRAME_PINNED) { direct[i] = true; continue; }
+        if (!(flags & FFV2AMD_FRAME_REGISTER) || q.linesize <= 0) continue;
+        const size_t need = (size_t)q.linesize * (size_t)(q.rows - 1) + q.row_bytes;
+        for (const auto &g : e->ring_reg)
+            if (g.base <= q.src && q.src + need <= g.base + g.bytes) { direct[i] = true; break; }
+        if (!direct[i] && e->ring_reg.size() < 256) {
+            if (hipHostRegister((void *)q.src, need, hipHostRegisterDefault) == hipSuccess) {
+                try { e->ring_reg.push_back({ q.src, need }); direct[i] = true; }
+                catch (...) { (void)hipHostUnregister((void *)q.src); }
+            } else {
+                (void)hipGetLastError();          // not registrable (already part of another registration, ...): gather it
+            }
         }
-    } else {
+    }
+    int ngather = 0;
+    for (int i = 0; i < npl; i++) {
+        const RingPlane &q = pl[i];
+        if (!direct[i]) { ngather++; continue; }
+        if (q.linesize == (ptrdiff_t)q.pitch)
+            HIPCHK(hipMemcpyAsync(q.d_dst, q.src, q.pitch * (size_t)(q.rows - 1) + q.row_bytes, hipMemcpyHostToDevice, sh));
+        else
+            HIPCHK(hipMemcpy2DAsync(q.d_dst, q.pitch, q.src, (size_t)q.linesize, q.row_bytes, (size_t)q.rows,
+                                    hipMemcpyHostToDevice, sh));
+    }
+    if (ngather) {
         // pageable planes: gather into the slot's pinned frame in slices of rows; every slice's DMA
         // is issued as soon as it is gathered (by the pool's threads when the picture is large)
         int first[5] = { 0, 0, 0, 0, 0 };
-        for (int i = 0; i < npl; i++) first[i + 1] = first[i] + (e->ring_pool ? pl[i].slices : 1);
+        for (int i = 0; i < npl; i++) first[i + 1] = first[i] + (direct[i] ? 0 : e->ring_pool ? pl[i].slices : 1);
         const int nsl = first[npl];
         hipError_t up[32];
         for (int i = 0; i < nsl; i++) up[i] = hipSuccess;

@@ -213,8 +213,8 @@ int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *fra
             s->ring_open = 1;
         }
         ret = flags & FFV2AMD_FRAME_YUV420
-            ? ffv2amd_ring_send_420(enc, frame->data, frame->linesize, NULL, frame->pts, flags & FFV2AMD_FRAME_PINNED)
-            : ffv2amd_ring_send(enc, frame->data, frame->linesize, NULL, frame->pts, flags & FFV2AMD_FRAME_PINNED);
+            ? ffv2amd_ring_send_420(enc, frame->data, frame->linesize, NULL, frame->pts, flags & (FFV2AMD_FRAME_PINNED | FFV2AMD_FRAME_REGISTER))
+            : ffv2amd_ring_send(enc, frame->data, frame->linesize, NULL, frame->pts, flags & (FFV2AMD_FRAME_PINNED | FFV2AMD_FRAME_REGISTER));
     }
     if (ret < 0)
         return ret;

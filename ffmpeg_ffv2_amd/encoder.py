@@ -398,10 +398,11 @@ class FFV2Encoder:
     def ring_pending(self):
         return self._lib.ffv2amd_ring_pending(self._h)
 
-    def ring_send(self, frame, tag=0, W=None, pinned=False):
+    def ring_send(self, frame, tag=0, W=None, pinned=False, register=False):
         """frame: (P,H,W) host array (any row stride).  Returns False when the ring is full
         (EAGAIN: receive a packet first).  pinned=True promises page-locked memory that stays
-        untouched until the frame's packet has been received."""
+        untouched until the frame's packet has been received; register=True: ordinary memory from a pool of
+        long-lived buffers, page-locked by the ring on first sight (FFV2AMD_FRAME_REGISTER)."""
         i = self.info
         assert frame.dtype == self.dtype and frame.shape == (i.planes, i.height, i.width), (frame.dtype, frame.shape)
         assert frame.strides[2] == self.dtype.itemsize
@@ -415,13 +416,13 @@ class FFV2Encoder:
             W = np.ascontiguousarray(W, np.int32)
             assert W.size == i.block_planes
             wp = W.ctypes.data_as(C.c_void_p)
-        r = self._lib.ffv2amd_ring_send(self._h, data, ls, wp, int(tag), 1 if pinned else 0)
+        r = self._lib.ffv2amd_ring_send(self._h, data, ls, wp, int(tag), (1 if pinned else 0) | (4 if register else 0))
         if r == -11:
             return False
         _lib.check(r, "ring_send")
         return True
 
-    def ring_send_420(self, y, u, v, tag=0, pinned=False):
+    def ring_send_420(self, y, u, v, tag=0, pinned=False, register=False):
         """A yuv420p* frame through the ring (Y (H,W); U, V (ceil(H/2), ceil(W/2)), any row stride): half the
         PCIe bytes of its 4:4:4 form, up-converted on the frame's compute stream.  False when the ring is full."""
         i = self.info
@@ -430,7 +431,7 @@ class FFV2Encoder:
             assert a.dtype == self.dtype and a.shape == shp and a.strides[1] == self.dtype.itemsize, (a.dtype, a.shape)
         data = (C.c_void_p * 3)(y.ctypes.data, u.ctypes.data, v.ctypes.data)
         ls = (C.c_ssize_t * 3)(y.strides[0], u.strides[0], v.strides[0])
-        r = self._lib.ffv2amd_ring_send_420(self._h, data, ls, None, int(tag), 1 if pinned else 0)
+        r = self._lib.ffv2amd_ring_send_420(self._h, data, ls, None, int(tag), (1 if pinned else 0) | (4 if register else 0))
         if r == -11:
             return False
         _lib.check(r, "ring_send_420")

@@ -292,6 +292,12 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
  *                  (status < 0) is dropped from the ring and its error returned. */
 #define FFV2AMD_FRAME_PINNED 1u
 #define FFV2AMD_FRAME_YUV420 2u      /* ffv2amd_codec_send_frame only: a 4:2:0 frame (== ffv2amd_ring_send_420) */
+#define FFV2AMD_FRAME_REGISTER 4u    /* the planes are ordinary (pageable) memory from a pool of long-lived buffers -- what
+                                        libavcodec's get_buffer2 hands out: the ring page-locks each distinct buffer the first
+                                        time it sees it (hipHostRegister, milliseconds) and lets the DMA engine read it in place
+                                        from then on, like FFV2AMD_FRAME_PINNED; same promise: untouched until the frame's packet
+                                        has been received, and the buffers outlive the ring (registrations end at ring_close;
+                                        at most 256 buffers, further ones are gathered like unflagged frames) */
 int   ffv2amd_ring_open(ffv2amd_encoder *enc, int depth);
 int   ffv2amd_ring_send(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
                         const int32_t *W, int64_t tag, unsigned flags);

@@ -70,7 +70,7 @@ int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:51
 /* avcodec_send_frame / avcodec_receive_packet (encode.c:420,449): asynchronous, up to ring_depth
  * frames in flight per device, FFV2AMD_ERR_AGAIN (= AVERROR(EAGAIN)) when full (receive a packet,
  * then send again) / nothing ready; packets in send order with the frame's pts, whichever device
- * finishes first.  flags: FFV2AMD_FRAME_PINNED, FFV2AMD_FRAME_YUV420 of ffv2_amd.h (the latter:
+ * finishes first.  flags: FFV2AMD_FRAME_PINNED, FFV2AMD_FRAME_REGISTER, FFV2AMD_FRAME_YUV420 of ffv2_amd.h (the last:
  * frame->data[0..2] = Y, U, V of a yuv420p* frame of the context's depth, see
  * ffv2amd_codec_encode_yuv420; global_quality 0 only).
  * global_quality 1..64 goes through ffv2amd_qp_send_frame / _receive_packet: two frames in flight per

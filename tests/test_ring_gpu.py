@@ -261,3 +261,42 @@ def test_upconv_tiled_and_per_sample_kernels_agree(oracle, monkeypatch):
         env = dict(os.environ, FFV2AMD_UPCONV_NAIVE=naive)
         r = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True)
         assert r.returncode == 0 and "ok" in r.stdout, (naive, r.stdout, r.stderr)
+
+
+def test_ring_registers_pooled_pageable_frames(oracle):
+    """FFV2AMD_FRAME_REGISTER: ordinary memory from a pool of long-lived buffers (what libavcodec's frame pools hand
+    out) is page-locked by the ring the first time it sees a buffer and read in place afterwards.  Same packets,
+    same order; new contents in a registered buffer are picked up; unflagged and 4:2:0 frames mix in."""
+    W, H, fmt, P, depth = 640, 360, "yuv444p10le", 3, 10
+    enc = _enc(W, H, fmt)
+    enc.ring_open(3)
+    pool = [np.zeros((P, H, W), "<u2") for _ in range(3)]              # the caller's frame pool
+    frames = [synth.make("S2" if n % 2 else "S1", n, P, H, W, depth) for n in range(10)]
+    want = [oracle.encode(f, fmt) for f in frames]
+    got, sent, free = [], 0, [0, 1, 2]
+    inflight = []
+    while len(got) < len(frames):
+        while sent < len(frames) and free:
+            b = free.pop(0)
+            pool[b][:] = frames[sent]                                  # the buffer is refilled only once its packet is out
+            assert enc.ring_send(pool[b], tag=sent, register=True)
+            inflight.append(b)
+            sent += 1
+        got.append(enc.ring_receive())
+        free.append(inflight.pop(0))
+    assert got == list(enumerate(want))
+    # a 4:2:0 frame from ordinary memory with the flag, an unflagged frame and a page-locked one behind it
+    rng = np.random.default_rng(3)
+    y, u, v = [rng.integers(0, 1 << depth, s).astype("<u2") for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2))]
+    pin = enc.pinned_frames(1)
+    pin[0] = frames[1]
+    assert enc.ring_send_420(y, u, v, tag=50, register=True) and enc.ring_send(frames[0], tag=51) and enc.ring_send(pin[0], tag=52, pinned=True)
+    assert enc.ring_receive() == (50, oracle.encode(oracle.sws_420_to_444(y, u, v, depth), fmt))
+    assert enc.ring_receive() == (51, want[0]) and enc.ring_receive() == (52, want[1])
+    enc.ring_close()                                                   # ends the registrations
+    enc.free_pinned()
+    enc.ring_open(2)                                                   # a new ring registers afresh
+    assert enc.ring_send(pool[0], tag=9, register=True)
+    assert enc.ring_receive()[0] == 9
+    enc.ring_close()
+    enc.close()

@@ -1356,44 +1356,43 @@ int ffv2amd_inverse_tstage_device(ffv2amd_encoder *e, int nframes, const int32_t
 // magnitudes (pow, sqrt: ffv2dec.c:91-98,134) are the host libm's.  Not a product decoder: a
 // self check for the encoder and the PSNR line of the report.  PARITY UNPINNED.
 // ------------------------------------------------------------------
-int ffv2amd_decode_frame(ffv2amd_encoder *e, const uint8_t *pkt, size_t size, uint8_t *const data[4],
-                         const ptrdiff_t linesize[4], unsigned flags, int *qp_out)
+// The host half of ffv2amd_decode_frame, callable without a GPU: the packet's entropy layer in the symbol order of
+// dequant_block.  pulses[bp][q]: what the decoder's pulses[] holds for coding position q when its band is scaled
+// (slots a band does not read keep earlier bands' values); mag[bp][b]: the band's scale (float)pow(gain, 1.5f) /
+// sqrt(sum of the squares of the pulses read: inf or NaN at qp 0); c0[bp]: the "DC" slot.
+int ffv2amd_parse_packet(const uint8_t *pkt, size_t size, int width, int height, int *pix_fmt_out, int *qp_out,
+                         int16_t *pulses, float *mag, int32_t *c0)
 {
-    if (!e || !pkt || !data || !linesize) return FFV2AMD_ERR_INVAL;
-    const ffv2amd_info &in = e->info;
-    for (int p = 0; p < in.planes; p++)
-        if (!data[p]) return FFV2AMD_ERR_INVAL;
-    const size_t nb = (size_t)in.block_planes;
-    std::vector<int16_t> pulses;
-    std::vector<float> mag;
-    std::vector<int32_t> c0;
+    if (!pkt || !pulses || !mag || !c0 || width < 1 || height < 1) return FFV2AMD_ERR_INVAL;
     std::vector<uint16_t> test;
-    std::vector<int> slot;
-    int qp = 0;
+    int slot[4097];
     try {
-        pulses.assign(nb * 4096, 0); mag.assign(nb * 13, 0.f); c0.assign(nb, 0); slot.assign(4097, 0);
         RangeDec d(pkt, size);
         const int pix_fmt = (int)d.uint_(196);                           // ffv2dec.c:276
-        qp = (int)d.golomb();                                            // :277
-        if (d.err || pix_fmt != in.pix_fmt || qp < 0 || qp > 16384) return FFV2AMD_ERR_INVAL;
+        const int qp = (int)d.golomb();                                  // :277
+        int planes, depth;
+        if (d.err || pixfmt_info(pix_fmt, &planes, &depth) < 0 || qp < 0 || qp > 16384) return FFV2AMD_ERR_INVAL;
+        if (pix_fmt_out) *pix_fmt_out = pix_fmt;
+        if (qp_out) *qp_out = qp;
         test.resize((size_t)13 * (qp > 0 ? qp : 1));
         for (int r = 0; r < 13; r++)
             for (int j = 0; j < qp; j++) test[(size_t)r * qp + j] = (uint16_t)(j + 1);
         uint16_t subdiv[4] = { 32, 64, 96, 128 };
-        const int nsb = in.num_sb_x * in.num_sb_y;
+        const int nsb = ((width + 63) / 64) * ((height + 63) / 64);
         for (int sb = 0; sb < nsb; sb++) {
             if (d.adapt(subdiv, 4, 128) != 0 || d.err) return FFV2AMD_ERR_INVAL;   // the encoder never splits
             (void)d.bits(4);                                             // tx type
-            for (int p = 0; p < in.planes; p++) {
-                const size_t bp = (size_t)sb * in.planes + p;
-                std::fill(slot.begin(), slot.end(), 0);                  // int pulses[4096] = { 0 }
+            for (int p = 0; p < planes; p++) {
+                const size_t bp = (size_t)sb * planes + p;
+                memset(slot, 0, sizeof(slot));                           // int pulses[4096] = { 0 }
+                memset(pulses + bp * 4096, 0, sizeof(int16_t) * 4096);
                 int32_t v = (int32_t)d.golomb();
                 if (v) v = (int32_t)((uint32_t)v * (uint32_t)(1 - 2 * (int)d.bits(1)));
                 c0[bp] = v;
                 for (int b = 0; b < 13; b++) {
                     const int lo = 1 + BANDS_START[b], len = BANDS_START[b + 1] - BANDS_START[b];
                     const float cg = (float)d.golomb();
-                    float m = (float)pow((double)(cg * 1), (double)1.5f);         // gain_expand(cg, 1, 1.5f)
+                    const float m = (float)pow((double)(cg * 1), (double)1.5f);   // gain_expand(cg, 1, 1.5f)
                     int cnt = 0, pcnt = 0;
                     for (int j = 0; j < len; j++) {
                         if (pcnt >= qp) break;
@@ -1411,6 +1410,30 @@ int ffv2amd_decode_frame(ffv2amd_encoder *e, const uint8_t *pkt, size_t size, ui
             }
         }
     } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_decode_frame(ffv2amd_encoder *e, const uint8_t *pkt, size_t size, uint8_t *const data[4],
+                         const ptrdiff_t linesize[4], unsigned flags, int *qp_out)
+{
+    if (!e || !pkt || !data || !linesize) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    for (int p = 0; p < in.planes; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    const size_t nb = (size_t)in.block_planes;
+    std::vector<int16_t> pulses;
+    std::vector<float> mag;
+    std::vector<int32_t> c0;
+    int qp = 0, pix_fmt = -1;
+    try { pulses.resize(nb * 4096); mag.assign(nb * 13, 0.f); c0.assign(nb, 0); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+    {
+        // the header decides how many planes the packet carries: it must be this encoder's format before the
+        // symbols are parsed into arrays sized for it
+        RangeDec h(pkt, size);
+        if ((int)h.uint_(196) != in.pix_fmt || h.err) return FFV2AMD_ERR_INVAL;
+    }
+    const int pr = ffv2amd_parse_packet(pkt, size, in.width, in.height, &pix_fmt, &qp, pulses.data(), mag.data(), c0.data());
+    if (pr < 0) return pr;
     if (qp_out) *qp_out = qp;
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;

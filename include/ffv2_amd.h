@@ -253,6 +253,13 @@ int  ffv2amd_inverse_tstage_device(ffv2amd_encoder *enc, int nframes, const int3
  * contains the decoding time and is not reproducible).  *qp_out: the packet's qp.  A self check and the
  * PSNR line of tools/fate_report.py, not a product decoder.  PARITY UNPINNED. */
 #define FFV2AMD_DECODE_GRID 1u
+/* The host half of ffv2amd_decode_frame on its own (no GPU): the packet's entropy layer in dequant_block's symbol order.
+ *   pulses int16 [nblk][4096]  the decoder's pulses[] value for every coding position when its band is scaled
+ *   mag    float [nblk][13]    (float)pow(gain, 1.5f) / sqrt(sum of squares of the pulses read) -- inf / NaN at qp 0
+ *   c0     int32 [nblk]        the "DC" slot
+ * sized by the caller for the planes of the format it expects; check *pix_fmt_out. */
+int  ffv2amd_parse_packet(const uint8_t *packet, size_t size, int width, int height, int *pix_fmt_out, int *qp_out,
+                          int16_t *pulses, float *mag, int32_t *c0);
 int  ffv2amd_decode_frame(ffv2amd_encoder *enc, const uint8_t *packet, size_t size, uint8_t *const data[4],
                           const ptrdiff_t linesize[4], unsigned flags, int *qp_out);
 

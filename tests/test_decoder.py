@@ -108,6 +108,46 @@ def test_grid_is_the_only_difference(oracle):
     assert (g[0][on] == 0).all() and (g[1][on] == 512).all() and (g[2][on] == 512).all()
 
 
+@pytest.mark.parametrize("fmt,P,H,W,depth", CASES)
+@pytest.mark.parametrize("qp", [0, 4, 16, 64])
+def test_capi_packet_parse_matches_oracle_without_a_gpu(oracle, fmt, P, H, W, depth, qp):
+    """ffv2amd_parse_packet, the host half of ffv2amd_decode_frame (range decoder + dequant_block's symbol order,
+    band scales with the host's pow / sqrt): scaled and stored the way the device kernel does it, the coefficients
+    equal the oracle decoder's."""
+    import ctypes as C
+    from ffmpeg_ffv2_amd import _lib
+    from tests.oracle_lib import PIX
+    lib = _lib.load()
+    pkt = None
+    for seed in range(21 + qp, 40 + qp):          # a noise frame the reference does not abort on
+        try:
+            pkt = oracle.encode(synth.noise(seed, P, H, W, depth), fmt, qp=qp)
+            break
+        except RuntimeError:
+            continue
+    assert pkt is not None
+    nb = ((W + 63) // 64) * ((H + 63) // 64) * P
+    pulses = np.zeros((nb, 4096), np.int16)
+    mag = np.zeros((nb, 13), np.float32)
+    c0 = np.zeros(nb, np.int32)
+    pf, q = C.c_int(-1), C.c_int(-1)
+    buf = np.frombuffer(pkt, np.uint8)
+    assert lib.ffv2amd_parse_packet(buf.ctypes.data_as(C.c_void_p), buf.size, W, H, C.byref(pf), C.byref(q),
+                                    pulses.ctypes.data_as(C.c_void_p), mag.ctypes.data_as(C.c_void_p),
+                                    c0.ctypes.data_as(C.c_void_p)) == 0
+    assert pf.value == PIX[fmt] and q.value == qp
+    band = np.searchsorted(np.array(BS[1:13]), np.arange(4095), side="right")        # band of coding index 1 + t
+    with np.errstate(invalid="ignore", over="ignore"):
+        v = pulses[:, 1:].astype(np.float32) * mag[:, band]
+    ok = np.isfinite(v) & (v > -2147483904.0) & (v < 2147483648.0)
+    coef = np.where(ok, np.trunc(np.where(ok, v, 0)), -2147483648).astype(np.int64)
+    want, _ = oracle.decode_coefficients(pkt, fmt, H, W)
+    assert np.array_equal(c0, want[:, 0]) and np.array_equal(coef, want[:, 1:].astype(np.int64))
+    # damaged input is refused, not crashed on
+    assert lib.ffv2amd_parse_packet(buf.ctypes.data_as(C.c_void_p), 2, W, H, None, None, pulses.ctypes.data_as(C.c_void_p),
+                                    mag.ctypes.data_as(C.c_void_p), c0.ctypes.data_as(C.c_void_p)) in (0, -22)
+
+
 # ---- GPU: the C-ABI's decoder-side check against the oracle's decoder ----
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt,P,H,W,depth", CASES + [("yuv444p", 3, 240, 320, 8)])

@@ -20,9 +20,15 @@ N > 1   : frames are independent (no inter-frame state, ffv2enc.c:461-469), so
 --qp N  : (not the BASELINE metric) the qp > 0 path with the whole entropy coder on the
           device, the range coder's serial chain running one frame per lane over many
           frames in flight (ffv2_lanecoder.hip): a step is one call over --frames-in-flight
-          device-resident frames, calls back to back; "chain" reports the chain kernel from
-          device events, cpu_baseline the oracle at the same qp.  --host-coder / --device-coder
-          select the older coders.  Parity unpinned for qp > 0.
+          device-resident frames (default: what 160 GB of coder scratch hold), calls back to
+          back; "chain" reports the chain kernels from device events, "roofline" the PVQ
+          search kernel against the f32 division rate, cpu_baseline the oracle at the same qp.
+          --host-coder / --device-coder select the older coders.  Parity unpinned for qp > 0.
+host_boundary : after the timed region, frames in HOST memory through the asynchronous ring
+          (SURVEY.md 8(d)'s wording of the metric, PCIe included): page-locked, pageable,
+          pageable from a registered pool; 4:4:4 and the literal yuv420p* formats.
+steady_state  : the same launch back to back for --steady-seconds after the timed region
+          (hundreds of timed launches; with and without timing events).
 
 Prints ONE JSON line on rank 0.
 """

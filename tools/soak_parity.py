@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU box: random-geometry soak of both T-stage kernels against the CPU oracle (bit-exact
 coefficients, energies and qp = 0 packets; qp > 0 and 4:2:0 cases on the way, the latter through
-the up-conversion kernel and through the frame ring).
+the up-conversion kernel and through the frame ring; frames with samples above their depth through the
+wide path; packets through the decoder-side check against the oracle's decoder).
 usage: python tools/soak_parity.py [seconds] [seed]
 tests/test_soak_gpu.py runs a fixed-seed slice of it (run(cases=...)) in the -m gpu suite."""
 import os
@@ -27,6 +28,7 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
     lib = _lib.load()
     rng = np.random.default_rng(seed)
     t0, n, nq, n420 = time.time(), 0, 0, 0
+    nwide = ndec = 0
     try:
         while (cases is None or n < cases) and (cases is not None or time.time() - t0 < budget):
             fmt, P, depth = FMTS[int(rng.integers(len(FMTS)))]
@@ -54,6 +56,21 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
                 co, eo = oracle.tstage(frames[k], fmt)
                 assert np.array_equal(coef[k], co) and np.array_equal(en[k], eo), ("tstage", fmt, W, H, F, mode, k)
                 assert got[k] == oracle.encode(frames[k], fmt), ("packet", fmt, W, H, F, mode, k)
+            if depth > 8 and rng.random() < 0.08:
+                # samples above the declared depth: the wide (plain int32) rerun + host-assembled packet (ffv2_wide.hip)
+                wild = frames[0].copy()
+                idx = rng.integers(0, wild.size, 1 + int(rng.integers(0, 6)))
+                wild.reshape(-1)[idx] = rng.integers(1 << depth, 65536, idx.size)
+                assert enc.encode2(wild) == oracle.encode(wild, fmt), ("wide", fmt, W, H, mode)
+                nwide += 1
+            if rng.random() < 0.1:
+                # decoder-side check of the packet just made (ffv2amd_decode_frame) against the oracle's decoder
+                pic, q0 = enc.decode(got[0], grid=bool(rng.integers(2)))
+                assert q0 == 0
+                ndec += 1
+                want_pic, _ = oracle.decode(got[0], fmt, H, W, grid=False)
+                on = (np.mgrid[0:H, 0:W][1] % 64 == 0) | (np.mgrid[0:H, 0:W][0] % 64 == 0)
+                assert np.array_equal(pic[:, ~on], want_pic[:, ~on]), ("decode", fmt, W, H)
             if rng.random() < p_qp and W * H < 200000:
                 qp = int(rng.choice([4, 16, 64]))
                 noise = np.stack([synth.noise(int(rng.integers(1 << 20)), P, H, W, depth) for _ in range(F)])
@@ -62,6 +79,11 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
                     pk = enc.encode_batch_to_host(enc.upload(noise), qp=qp)
                     for k in range(F):
                         assert pk[k] == oracle.encode(noise[k], fmt, qp=qp), ("qp", qp, fmt, W, H, mode, k)
+                    if rng.random() < 0.3:
+                        pic, q0 = enc.decode(pk[0])
+                        want_pic, _ = oracle.decode(pk[0], fmt, H, W)
+                        assert q0 == qp and np.array_equal(pic, want_pic), ("decode qp", qp, fmt, W, H)
+                        ndec += 1
                 except _lib.FFV2Error as ex:            # the reference would abort: the oracle must say so too
                     assert ex.code == -1
                     bad = False
@@ -92,6 +114,8 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
                 print("  ... %d geometries, %.0f s" % (n, time.time() - t0), flush=True)
     finally:
         lib.ffv2amd_debug_force_tstage(-1)
+    if not quiet:
+        print("  (%d frames above their depth through the wide path, %d packets through the decoder-side check)" % (nwide, ndec))
     return n, nq, n420
 
 

@@ -646,6 +646,8 @@ struct ffv2amd_encoder {
         uint32_t *d_pk_sizes = nullptr, *h_pk_sizes = nullptr;
         int32_t *d_pk_status = nullptr, *h_pk_status = nullptr;
         bool on_device = false;          // this batch was coded by the device coder
+        const uint8_t *d_frames = nullptr;   // the batch's frames and phantom words: a frame the fast T-stage refuses is rerun wide at finish
+        const int32_t *d_W = nullptr;
     };
     bool device_coder = false;
     QpSet qset[2];
@@ -1943,6 +1945,7 @@ int ffv2amd_qp_submit(ffv2amd_encoder *e, int nframes, const void *d_frames, int
     HIPCHK(ffv2_launch_tstage(a, s));
     HIPCHK(ffv2_launch_pvq(e->d_coef_ws, d_W, e->d_y, qp, (long long)nb * nframes, s));
     HIPCHK(ffv2_launch_compact(e->d_y, qp, (int)nb, nframes, q.d_rec, q.d_stream, e->q_stream_stride, q.d_totals, s));
+    q.d_frames = (const uint8_t *)d_frames; q.d_W = d_W;
     q.on_device = e->device_coder;
     if (q.on_device) {
         // the whole entropy coder on the device: one wavefront per frame (ffv2_rangecoder.hip)
@@ -2005,6 +2008,42 @@ int ffv2amd_qp_finish(ffv2amd_encoder *e, uint8_t *h_packets, size_t packet_stri
         q.busy = false;
         e->q_fin++;
         return FFV2AMD_OK;
+    }
+    // A frame the fast T-stage refused (samples above the declared depth, a gain beyond the device table) is coded by
+    // the reference all the same (ffv2.c:26-38, ffv2enc.c:163-174): rerun it through the wide T-stage, the PVQ search and
+    // the compaction (all take any int32 coefficient), take its gains with the host's pow, and let the host coder below
+    // treat it like the others.  Synchronous, on the encoder's stream: the frames are still the caller's to keep alive.
+    for (int f = 0; f < nframes; f++) {
+        if (q.h_status[f] != FFV2AMD_ERR_RANGE) continue;
+        hipStream_t s = e->stream;
+        int32_t *coef = e->d_coef_ws + (size_t)f * nb * 4096;
+        int16_t *y = e->d_y + (size_t)f * nb * FFV2_Y_STRIDE;
+        const int32_t *dW = q.d_W ? q.d_W + (size_t)f * nb : nullptr;
+        int r = wide_tstage(e, q.d_frames + (size_t)f * in.frame_stride, coef, s);
+        if (r < 0) return r;
+        HIPCHK(ffv2_launch_pvq(coef, dW, y, qp, (long long)nb, s));
+        HIPCHK(hipMemsetAsync(q.d_totals + f, 0, sizeof(uint32_t), s));
+        HIPCHK(ffv2_launch_compact(y, qp, (int)nb, 1, q.d_rec + (size_t)f * nb, q.d_stream + (size_t)f * e->q_stream_stride,
+                                   e->q_stream_stride, q.d_totals + f, s));
+        std::vector<int64_t> en;
+        std::vector<int32_t> c0, W;
+        try { en.resize(nb * 13); c0.resize(nb); if (dW) W.resize(nb); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+        HIPCHK(hipMemcpyAsync(en.data(), e->d_wide_en, sizeof(int64_t) * en.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(c0.data(), e->d_wide_c0, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
+        if (dW) HIPCHK(hipMemcpyAsync(W.data(), dW, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(q.h_rec + (size_t)f * nb, q.d_rec + (size_t)f * nb, sizeof(FFV2SymRec) * nb, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(q.h_totals + f, q.d_totals + f, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        uint32_t *codes = q.h_codes + (size_t)f * nb * FFV2_CODES_PER_BP;
+        for (size_t bp = 0; bp < nb; bp++) {
+            codes[bp * FFV2_CODES_PER_BP] = (uint32_t)c0[bp];
+            for (int b = 0; b < 13; b++) {
+                int64_t eb = en[bp * 13 + b];
+                if (b == 12 && dW) eb = (int64_t)((uint64_t)eb + (uint64_t)((int64_t)W[bp] * W[bp]));
+                codes[bp * FFV2_CODES_PER_BP + 1 + b] = coded_gain_host(eb);
+            }
+        }
+        q.h_status[f] = 0;
     }
     // each frame's symbol stream: its own size, on the copy stream, one event per frame
     for (int f = 0; f < nframes; f++) {

@@ -118,10 +118,11 @@ int  ffv2amd_tstage_device(ffv2amd_encoder *enc, int nframes, const void *d_fram
  * any 16-bit sample (ffv2.c:26-38 level-shifts whatever it is given).  The fast kernels stage samples
  * as int16 and refuse a frame with samples above its declared depth, or a band gain beyond their
  * 32 768-entry table, with FFV2AMD_ERR_RANGE in the frame's status; the entry points that end in host
- * memory at qp == 0 (ffv2amd_encode_frame, _encode_frame_420, _encode_batch_to_host, _ring_receive,
- * the codec shim) then rerun that frame through this path and assemble its packet on the host, so
- * the caller gets the reference's packet, not an error.  ffv2amd_encode_batch_device (packets stay in
- * HBM, no host in the loop) and every qp > 0 path report the status instead.  Outputs as
+ * memory (ffv2amd_encode_frame, _encode_frame_420, _encode_batch_to_host, _ring_receive, _qp_finish with
+ * the host coder, the codec shim) then rerun that frame through this path -- at qp > 0 followed by the PVQ
+ * search, which takes any int32 coefficient -- and code it on the host, so the caller gets the reference's
+ * packet, not an error.  ffv2amd_encode_batch_device (packets stay in HBM, no host in the loop) and the
+ * device coders of qp > 0 (lane coder, one-wavefront coder) report the status instead.  Outputs as
  * ffv2amd_tstage_device; a test hook. */
 int  ffv2amd_tstage_wide_device(ffv2amd_encoder *enc, const void *d_frame, int32_t *d_coef, int64_t *d_energy,
                                 void *stream);

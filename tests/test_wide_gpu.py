@@ -96,3 +96,45 @@ def test_yuv420_luma_above_depth(oracle):
     assert enc.ring_receive() == (4, want)
     enc.ring_close()
     enc.close()
+
+
+@pytest.mark.parametrize("qp", [4, 16])
+def test_wide_path_at_qp_above_zero(oracle, qp):
+    """global_quality > 0 on frames above their depth: wide T-stage -> PVQ search -> host coder, through encode2, the
+    batch entry and send_frame / receive_packet; a well-formed neighbour in the same batch is untouched.  (Parity
+    unpinned like all of qp > 0.)"""
+    import ctypes as C
+    from ffmpeg_ffv2_amd import _lib
+    from tests.codec_ctypes import Packet, frame_of, make_ctx
+    H, W, fmt, depth = 130, 200, "yuv444p10le", 10
+    enc = _enc(W, H, fmt, max_batch=3)
+    good = synth.noise(3, 3, H, W, depth)
+    wild = want_w = None
+    for seed in range(40):                        # noise with a handful of samples above the depth that the reference codes
+        cand = synth.noise(100 + seed, 3, H, W, depth).copy()   # without aborting (daala_entropy.c:336) at this qp
+        idx = np.random.default_rng(seed).integers(0, cand.size, 12)
+        cand.reshape(-1)[idx] = np.random.default_rng(seed + 1).integers(1 << depth, 65536, 12)
+        try:
+            want_w = oracle.encode(cand, fmt, qp=qp)
+            wild = cand
+            break
+        except RuntimeError:
+            continue
+    assert wild is not None
+    want_g = oracle.encode(good, fmt, qp=qp)
+    assert enc.encode2(wild, qp=qp) == want_w
+    Wp = (np.arange(enc.info.block_planes, dtype=np.int32) * 7919) % 50
+    assert enc.encode2(wild, qp=qp, W=Wp) == oracle.encode(wild, fmt, qp=qp, W=Wp)
+    assert enc.encode_batch_to_host(enc.upload(np.stack([good, wild, good])), qp=qp) == [want_g, want_w, want_g]
+    enc.close()
+    lib = _lib.load()
+    ctx = make_ctx(W, H, 70, qp=qp)
+    assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
+    for n, fr in enumerate((good, wild)):
+        assert lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(fr, 40 + n)), 0) == 0
+    for n, want in enumerate((want_g, want_w)):
+        pkt = Packet()
+        assert lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(pkt), 1) == 0
+        assert pkt.pts == 40 + n and bytes(pkt.data[: pkt.size]) == want
+        lib.ffv2amd_packet_unref(C.byref(pkt))
+    assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0

@@ -657,6 +657,7 @@ struct ffv2amd_encoder {
     // host frames through that pipeline (ffv2amd_qp_send_frame / _receive_packet): one frame per batch
     uint8_t *qh_frame[2] = { nullptr, nullptr }, *qd_frame[2] = { nullptr, nullptr };
     int32_t *qd_w[2] = { nullptr, nullptr };
+    uint8_t *qd_c420[2] = { nullptr, nullptr };          // U, V of a 4:2:0 frame (ffv2amd_qp_send_frame_420)
     int64_t q_tag[2] = { 0, 0 };
     // decoder-side check (ffv2amd_decode_frame)
     int16_t *d_dec_pulses = nullptr;
@@ -827,7 +828,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     }
     if (e->q_copy) { (void)hipStreamSynchronize(e->q_copy); (void)hipStreamDestroy(e->q_copy); }
     for (int k = 0; k < 2; k++) {
-        (void)hipFree(e->qd_frame[k]); (void)hipFree(e->qd_w[k]);
+        (void)hipFree(e->qd_frame[k]); (void)hipFree(e->qd_w[k]); (void)hipFree(e->qd_c420[k]);
         if (e->qh_frame[k]) (void)hipHostFree(e->qh_frame[k]);
     }
     (void)hipFree(e->d_thr); (void)hipFree(e->d_lds_scan); (void)hipFree(e->d_prefix);
@@ -2121,6 +2122,46 @@ int ffv2amd_qp_send_frame(ffv2amd_encoder *e, const uint8_t *const data[4], cons
         dW = e->qd_w[k];
     }
     const int r = ffv2amd_qp_submit(e, 1, e->qd_frame[k], qp, dW);
+    if (r < 0) return r;
+    e->q_tag[k] = tag;
+    return FFV2AMD_OK;
+}
+
+// The same for a yuv420p* frame (data[0..2] = Y, U, V): the ffmpeg tool's format step (ffv2_upconv.hip) on the encoder's
+// stream in front of the T-stage, as ffv2amd_ring_send_420 does for qp 0.  Parity unpinned twice over.
+int ffv2amd_qp_send_frame_420(ffv2amd_encoder *e, const uint8_t *const data[3], const ptrdiff_t linesize[3], int qp, int64_t tag)
+{
+    if (!e || !data || !linesize || !data[0] || !data[1] || !data[2]) return FFV2AMD_ERR_INVAL;
+    if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
+    if (e->q_sub - e->q_fin >= 2) return FFV2AMD_ERR_AGAIN;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    int r = upconv_ready(e);
+    if (r < 0) return r;
+    const ffv2amd_info &in = e->info;
+    const int k = (int)(e->q_sub & 1u);
+    const size_t bps = in.depth > 8 ? 2 : 1;
+    const int cw = (in.width + 1) >> 1, ch = (in.height + 1) >> 1;
+    const size_t c_pitch = align_up((size_t)cw * bps, 128);
+    if (!e->qd_frame[k]) {
+        HIPCHK(hipMalloc(&e->qd_frame[k], in.frame_stride));
+        HIPCHK(hipMalloc(&e->qd_w[k], sizeof(int32_t) * in.block_planes));
+        HIPCHK(hipHostMalloc(&e->qh_frame[k], in.frame_stride, hipHostMallocDefault));
+        memset(e->qh_frame[k], 0, in.frame_stride);
+    }
+    if (!e->qd_c420[k]) HIPCHK(hipMalloc(&e->qd_c420[k], 2 * c_pitch * (size_t)ch));
+    // staging: luma in plane 0 of the page-locked frame, U and V behind it (they fit planes 1 and 2, see ring_send_420)
+    uint8_t *hy = e->qh_frame[k], *hc = e->qh_frame[k] + in.plane_stride;
+    for (int y = 0; y < in.height; y++)
+        memcpy(hy + (size_t)y * in.row_pitch, data[0] + (ptrdiff_t)y * linesize[0], (size_t)in.width * bps);
+    for (int p = 0; p < 2; p++)
+        for (int y = 0; y < ch; y++)
+            memcpy(hc + ((size_t)p * ch + y) * c_pitch, data[1 + p] + (ptrdiff_t)y * linesize[1 + p], (size_t)cw * bps);
+    hipStream_t s = e->stream;
+    HIPCHK(hipMemcpyAsync(e->qd_frame[k], hy, in.row_pitch * (size_t)in.height, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->qd_c420[k], hc, 2 * c_pitch * (size_t)ch, hipMemcpyHostToDevice, s));
+    HIPCHK(ffv2_launch_upconv_chroma(e->upconv, e->geom, 1, e->qd_c420[k], c_pitch, c_pitch * (size_t)ch, 0, e->qd_frame[k], s));
+    r = ffv2amd_qp_submit(e, 1, e->qd_frame[k], qp, nullptr);
     if (r < 0) return r;
     e->q_tag[k] = tag;
     return FFV2AMD_OK;

@@ -199,9 +199,9 @@ int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *fra
         return FFV2AMD_ERR_INVAL;               /* global_quality changed with frames in flight */
     enc = s->encs[s->sent % (uint64_t)s->ndev];
     if (qp > 0) {
-        if (flags & FFV2AMD_FRAME_YUV420)
-            return FFV2AMD_ERR_UNSUPPORTED;
-        ret = ffv2amd_qp_send_frame(enc, frame->data, frame->linesize, qp, NULL, frame->pts);
+        ret = flags & FFV2AMD_FRAME_YUV420
+            ? ffv2amd_qp_send_frame_420(enc, frame->data, frame->linesize, qp, frame->pts)
+            : ffv2amd_qp_send_frame(enc, frame->data, frame->linesize, qp, NULL, frame->pts);
     } else {
         if (!s->ring_open) {
             for (int d = 0; d < s->ndev; d++)

@@ -179,6 +179,8 @@ int  ffv2amd_qp_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_s
  * the pipeline.  Do not mix with ffv2amd_qp_submit on one encoder.  Parity unpinned (qp > 0). */
 int  ffv2amd_qp_send_frame(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
                            int qp, const int32_t *W, int64_t tag);
+/* a yuv420p* frame (Y, U, V) through the same pipeline, up-converted on the device first (see ffv2amd_ring_send_420) */
+int  ffv2amd_qp_send_frame_420(ffv2amd_encoder *enc, const uint8_t *const data[3], const ptrdiff_t linesize[3], int qp, int64_t tag);
 int  ffv2amd_qp_receive_packet(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag);
 int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
 

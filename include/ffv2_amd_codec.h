@@ -72,7 +72,7 @@ int  ffv2amd_codec_close(FFV2AMDCodecContext *avctx);            /* ffv2enc.c:51
  * then send again) / nothing ready; packets in send order with the frame's pts, whichever device
  * finishes first.  flags: FFV2AMD_FRAME_PINNED, FFV2AMD_FRAME_REGISTER, FFV2AMD_FRAME_YUV420 of ffv2_amd.h (the last:
  * frame->data[0..2] = Y, U, V of a yuv420p* frame of the context's depth, see
- * ffv2amd_codec_encode_yuv420; global_quality 0 only).
+ * ffv2amd_codec_encode_yuv420).
  * global_quality 1..64 goes through ffv2amd_qp_send_frame / _receive_packet: two frames in flight per
  * device, receive_packet always waits (it runs the frame's range coder), a frame the reference
  * would abort on comes back as FFV2AMD_ERR_ABORT.  global_quality must not change while frames

@@ -178,3 +178,22 @@ def test_bench_starts_its_own_ranks():
     assert res["n_gpus"] == 2 and res["scaling"] == "weak"
     hb = res["host_boundary"]
     assert hb["ranks_seen"] == 2 and hb["packets_gathered"] == 12 and hb["packets_match_device_path"]
+
+
+def test_yuv420_frames_at_qp_above_zero(oracle):
+    """4:2:0 sources at global_quality > 0: up-conversion + qp pipeline behind send_frame / receive_packet."""
+    lib = _lib()
+    W, H, depth, qp = 200, 130, 8, 16
+    rng = np.random.default_rng(4)
+    src = [[rng.integers(0, 1 << depth, s).astype(np.uint8) for s in ((H, W), (H // 2, W // 2), (H // 2, W // 2))] for _ in range(4)]
+    ctx = make_ctx(W, H, 5, qp=qp, devices=[0, 0])
+    assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
+    got = _drive(lib, ctx, src, flags=FRAME_YUV420)
+    for n, (pts, pk) in enumerate(got):
+        conv = oracle.sws_420_to_444(*src[n], depth)
+        try:
+            want = oracle.encode(conv, "yuv444p", qp=qp)
+        except RuntimeError:
+            want = None
+        assert (pts, pk) == ((500 + n, want) if want is not None else (None, -1)), n
+    assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0

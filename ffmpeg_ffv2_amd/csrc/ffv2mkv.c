@@ -214,17 +214,20 @@ int ffv2amd_mkv_open(ffv2amd_mkv **out, const char *path, int width, int height,
     b.n = 0;
     r |= put_master(&b, ID_TRACKENTRY, &t);
     r |= put_master(&tracks, ID_TRACKS, &b);
-    /* SeekHead in front (matroskaenc.c:1881-1894 mkv_start_seekhead / :520-560 mkv_write_seekhead): where
-     * Info and Tracks start, relative to the first byte of the segment's data.  Both follow the
-     * SeekHead directly, so its own size is part of the positions: 4-byte positions keep it fixed.
-     * (The stock muxer also reserves a Void behind it and, for tracks with key frames, adds Cues at
-     * the end; FFV2 packets carry no key-frame flag, ffv2enc.c never sets AV_PKT_FLAG_KEY, so a stock
-     * file has no Cues either.) */
+    /* SeekHead in front (matroskaenc.c:1881-1894 mkv_start_seekhead / :463-517 mkv_write_seekhead): where
+     * Info and Tracks start, relative to the first byte of the segment's data.  The stock muxer reserves
+     * room for 10 entries there (10 * MAX_SEEKENTRY_SIZE + 19 = 229 bytes, :170,439), fills in the SeekHead
+     * when it finishes and leaves the rest as an EBML Void (:509-513, put_ebml_void :294-309): same here, so
+     * Info starts 229 bytes into the segment as in a stock file.  (For tracks with key frames the stock
+     * muxer also adds Cues at the end; FFV2 packets carry no key-frame flag -- ffv2enc.c never sets
+     * AV_PKT_FLAG_KEY and the codec descriptor has no INTRA_ONLY property, codec_desc.c:1757-1763 -- so a
+     * stock file has no Cues either.) */
     {
         const uint32_t ids[2] = { ID_INFO, ID_TRACKS };
+        const size_t reserved = 10 * 21 + 19;
         const size_t entry = id_bytes(ID_SEEKENTRY) + 1 + (id_bytes(ID_SEEKID) + 1 + 4) + (id_bytes(ID_SEEKPOSITION) + 1 + 4);
         const size_t seekhead_size = id_bytes(ID_SEEKHEAD) + 1 + 2 * entry;
-        const size_t pos[2] = { seekhead_size, seekhead_size + info.n };
+        const size_t pos[2] = { reserved, reserved + info.n };
         for (int i = 0; i < 2; i++) {
             const uint8_t idb[4] = { (uint8_t)(ids[i] >> 24), (uint8_t)(ids[i] >> 16), (uint8_t)(ids[i] >> 8), (uint8_t)ids[i] };
             const uint8_t pb[4] = { (uint8_t)(pos[i] >> 24), (uint8_t)(pos[i] >> 16), (uint8_t)(pos[i] >> 8), (uint8_t)pos[i] };
@@ -235,6 +238,15 @@ int ffv2amd_mkv_open(ffv2amd_mkv **out, const char *path, int width, int height,
         }
         r |= put_master(&file, ID_SEEKHEAD, &seek);
         if (!r && file.n - (size_t)m->segment_data_pos != seekhead_size) r = -EINVAL;
+        if (!r && seekhead_size + 10 > reserved) r = -EINVAL;
+        if (!r) {
+            /* Void over what is left of the reservation: id 0xEC, an 8-byte size field (size >= 10), zeros */
+            const size_t vsize = reserved - seekhead_size;
+            uint8_t hdr[9] = { 0xEC, 0x01, 0, 0, 0, 0, 0, 0, (uint8_t)(vsize - 9) };
+            static const uint8_t zeros[256];
+            r |= buf_put(&file, hdr, 9);
+            r |= buf_put(&file, zeros, vsize - 9);
+        }
     }
     const size_t info_at = file.n;
     r |= buf_put(&file, info.p, info.n);

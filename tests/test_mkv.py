@@ -40,7 +40,10 @@ def test_header_tracks_and_payloads(tmp_path):
     assert ebml == {"EBMLVersion": 1, "EBMLReadVersion": 1, "EBMLMaxIDLength": 4, "EBMLMaxSizeLength": 8,
                     "DocType": "matroska", "DocTypeVersion": 4, "DocTypeReadVersion": 2}
     seg = tree[1][1]
-    assert [n for n, _ in seg][:3] == ["SeekHead", "Info", "Tracks"]
+    # SeekHead + Void fill the 229 bytes the stock muxer reserves (matroskaenc.c:170,439,509-513), Info follows
+    assert [n for n, _ in seg][:4] == ["SeekHead", "Void", "Info", "Tracks"]
+    void = E.child(seg, "Void")
+    assert set(void) <= {0}
     # the SeekHead's positions (relative to the segment's first data byte) land on the elements they name
     seg_id0 = data.index(bytes.fromhex("18538067"))
     _, seg_data = E.read_size(data, seg_id0 + 4)
@@ -49,6 +52,7 @@ def test_header_tracks_and_payloads(tmp_path):
     for s in seeks:
         at = seg_data + s["SeekPosition"]
         assert data[at:at + 4] == s["SeekID"]
+    assert seeks[0]["SeekPosition"] == 10 * 21 + 19
     info = dict(E.child(seg, "Info"))
     assert info["TimecodeScale"] == 1000000
     assert info["Duration"] == 200.0                       # 5 frames at 25 fps, in ms

@@ -1520,6 +1520,8 @@ static uint32_t lanecoder_window(size_t maxsym16)
     uint64_t w = g_lc_window ? g_lc_window : env ? env : (1u << 18);
     w = (w + 15) / 16 * 16;
     if (w < 16) w = 16;
+    const uint64_t least = ((uint64_t)maxsym16 / 4096 + 15) / 16 * 16;     // never more than ~4 096 windows (two launches each)
+    if (w < least) w = least;
     if (w > maxsym16) w = maxsym16;
     return (uint32_t)w;
 }

@@ -293,7 +293,10 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
  *   ring_send    : FFV2AMD_ERR_AGAIN when `depth` frames are in flight (receive one first).
  *                  flags & FFV2AMD_FRAME_PINNED: the planes are page-locked (ffv2amd_host_alloc,
  *                  hipHostMalloc/hipHostRegister) and stay untouched until the frame's packet has
- *                  been received -- the DMA engine then reads them in place; otherwise the rows
+ *                  been received -- the DMA engine then reads them in place (planes that follow
+ *                  each other in memory without a gap, rows at the device pitch, travel as ONE copy:
+ *                  they must then belong to one page-locked allocation, as the planes of an
+ *                  ffv2amd_host_alloc / av_image_alloc style frame do); otherwise the rows
  *                  are gathered into a pinned staging frame before send returns, by a pool of
  *                  host threads the ring owns (FFV2AMD_GATHER_THREADS, caller included; default 6)
  *                  that is started on the first such send and joined by ring_close.

@@ -1777,9 +1777,16 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
         t.bitcnt = e->d_bitoff; t.W = d_W ? d_W + (size_t)f0 * nb : nullptr;
         t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = q.d_status_in + f0;
         HIPCHK(ffv2_launch_tstage(t, s));
-        HIPCHK(ffv2_launch_pvq(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, s));
+        // the search also notes what the coder will read of every band (FFV2AMD_LC_COUNT_KERNEL=1: a pass of its own
+        // over the pulses finds out, as before round 3; same numbers)
+        const bool count_pass = getenv("FFV2AMD_LC_COUNT_KERNEL") && atoi(getenv("FFV2AMD_LC_COUNT_KERNEL")) != 0;   // read per call: tests flip it
+        if (count_pass)
+            HIPCHK(ffv2_launch_pvq(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, s));
+        else
+            HIPCHK(ffv2_launch_pvq_counted(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, (int)nb, t.codes,
+                                           a.cnt + (size_t)f0 * nb, a.bits + (size_t)f0 * nb, a.abort_ + f0, s));
         a.f0 = f0;
-        HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, s));
+        HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, !count_pass, s));
     }
     HIPCHK(hipEventRecord(q.ev_front, s));
     // back: cdf and chain window by window, then the packets.  One call's back runs at a time (its

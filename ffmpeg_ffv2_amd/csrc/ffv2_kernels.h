@@ -71,6 +71,8 @@ struct FFV2SymRec {
 hipError_t ffv2_launch_compact(const int16_t *y, int qp, int nblk, int nframes, FFV2SymRec *rec, int8_t *stream,
                                size_t stream_stride, uint32_t *totals, hipStream_t s);
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s);
+hipError_t ffv2_launch_pvq_counted(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, int nblk,
+                                   const uint32_t *codes, FFV2SymRec *cnt, uint32_t *bits, int32_t *abort_, hipStream_t s);
 hipError_t ffv2_launch_pvq_vectors(const float *X, int stride, int N, int K, int count, int16_t *y, hipStream_t s);
 hipError_t ffv2_launch_estage_qp0(const FFV2EStageArgs &a, hipStream_t s);
 
@@ -142,7 +144,7 @@ struct FFV2LaneCoderArgs {
     unsigned long long *offs;         // [F + 1] packet offsets, [F] = bytes in all
     uint4 *fin;                       // [F] range bytes, slack bits, bytes the carry chain covers
 };
-hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s);   // count, scan, scatter of frames f0..
+hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, bool counted, hipStream_t s);   // count, scan, scatter of frames f0..
 // the back of frames 0..nframes-1, window by window (symbols [w0, w1) of every frame, record buffer buf), then finish
 hipError_t ffv2_launch_lc_cdf(const FFV2LaneCoderArgs &a, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t s);
 hipError_t ffv2_launch_lc_chain(const FFV2LaneCoderArgs &a, int nframes, uint32_t w0, uint32_t w1, int buf, hipStream_t s);

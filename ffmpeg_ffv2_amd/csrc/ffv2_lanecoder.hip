@@ -202,13 +202,25 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
         const unsigned long long code = golomb_code(cr[1 + b], &len);
         put(code, len);
         uint8_t *dst = rows + rowoff + rb;
-        for (uint32_t j0 = 0; j0 < cntb; j0 += 64) {
-            const uint32_t j = j0 + (uint32_t)lane;
-            const int q = j < cntb ? yy[lo + j] : 0;
-            if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
-            const unsigned long long nzm = __ballot(q != 0);
-            if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
-            pos += (uint32_t)__popcll(nzm);
+        // eight rows of 64 pulses at a time: their loads are in flight together (the kernel is the latency of its
+        // loads: one row per trip was 64 trips per block-plane on noise)
+        for (uint32_t j0 = 0; j0 < cntb; j0 += 512) {
+            int qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
+                qv[u] = j < cntb ? yy[lo + j] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
+                if (j0 + 64u * (uint32_t)u >= cntb) break;
+                const int q = qv[u];
+                if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
+                const unsigned long long nzm = __ballot(q != 0);
+                if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
+                pos += (uint32_t)__popcll(nzm);
+            }
         }
         rowoff += rowbase[(size_t)b * (nb + 1) + nb];
         before += cntb;
@@ -462,6 +474,10 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)maxt, o, 64); maxt = t > maxt ? t : maxt; }
     if (maxt == 0) return;                                             // no frame of this group reaches into the window
+    // The chain is latency, not throughput: one instruction every few cycles per wavefront.  Beside the front of the
+    // next call (PVQ search: three wavefronts per SIMD) it must win every issue slot it asks for, or its windows take
+    // 48 ms instead of 26; the others lose next to nothing.
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) { produced = 0; consumed = 0; }
     __syncthreads();
     // the two tile counters: relaxed workgroup-scope LDS accesses, ordered against the ring by hand
@@ -663,13 +679,15 @@ __global__ __launch_bounds__(256) void lc_write_kernel(const FFV2LaneCoderArgs a
 
 }  // namespace
 
-hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, hipStream_t s)
+hipError_t ffv2_launch_lc_front(const FFV2LaneCoderArgs &a, const int16_t *y, int nframes, bool counted, hipStream_t s)
 {
-    // a.f0 = index of the first of these frames among the frames in flight; y holds only these frames
+    // a.f0 = index of the first of these frames among the frames in flight; y holds only these frames.
+    // counted: a.cnt / a.bits / a.abort_ of these frames are filled in already (ffv2_launch_pvq_counted)
     const size_t nb = (size_t)a.nblk;
-    hipLaunchKernelGGL(lc_count_kernel, dim3((unsigned)a.nblk, (unsigned)nframes), dim3(64), 0, s,
-                       y, a.codes + (size_t)a.f0 * nb * FFV2_CODES_PER_BP, a.qp, a.nblk,
-                       a.cnt + (size_t)a.f0 * nb, a.bits + (size_t)a.f0 * nb, a.abort_ + a.f0);
+    if (!counted)
+        hipLaunchKernelGGL(lc_count_kernel, dim3((unsigned)a.nblk, (unsigned)nframes), dim3(64), 0, s,
+                           y, a.codes + (size_t)a.f0 * nb * FFV2_CODES_PER_BP, a.qp, a.nblk,
+                           a.cnt + (size_t)a.f0 * nb, a.bits + (size_t)a.f0 * nb, a.abort_ + a.f0);
     hipLaunchKernelGGL(lc_scan_kernel, dim3(15, (unsigned)nframes), dim3(64), 0, s, a);
     hipLaunchKernelGGL(lc_scatter_kernel, dim3((unsigned)a.nblk, (unsigned)nframes), dim3(64), 0, s, a, y);
     return hipGetLastError();

@@ -39,10 +39,45 @@ __device__ __forceinline__ float hsum4(float c0, float c1, float c2, float c3)  
     return __fadd_rn(__fadd_rn(c0, c2), __fadd_rn(c1, c3));
 }
 
+// What the range coder will do with a band (ffv2enc.c:175-186): it reads pulses until their magnitudes add
+// up to qp (`stop` symbols, all N if they never do), appends a sign bit for each non-zero one (`nz`), and
+// asserts when a magnitude reaches the alphabet size (daala_entropy.c:336; `big`).  Wave-uniform.
+struct PvqBandCount { int stop, nz; bool big; };
+
+// The same from the pulses in memory, 64 at a time: for the case the search cannot produce (more than K
+// pulses in a band), kept so that whatever a band holds is counted as the coder would read it.
+__device__ __noinline__ PvqBandCount pvq_count_from_memory(const int16_t *yy, int N, int K, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    PvqBandCount r{ N, 0, false };
+    int run = 0;
+    for (int j0 = 0; j0 < N && r.stop == N; j0 += 64) {
+        const int j = j0 + lane;
+        int a = j < N ? yy[j] : 0;
+        a = a < 0 ? -a : a;
+        int incl = a;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const unsigned long long hit = __ballot(run + incl >= K);
+        int end = N;
+        if (hit) { r.stop = j0 + __ffsll((long long)hit); end = r.stop; }
+        r.nz += (int)__popcll(__ballot(j < end && a > 0));
+        r.big = r.big || __ballot(j < end && a >= K) != 0;
+        run += __shfl(incl, 63, 64);
+    }
+    if (r.stop > N) r.stop = N;
+    return r;
+}
+
 // M = elements per lane (ceil(N4 / 64)).  x[m] = normalised coefficient of element
 // i = lane + 64 m (0 beyond N).  Writes y[i] for i < N.
 template <int M>
-__device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, int lane, int16_t *yout)
+__device__ PvqBandCount pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, int lane, int16_t *yout)
 {
     const int nv = (N + 3) >> 2, N4 = nv * 4;
     float ax[M], fy[M];
@@ -64,7 +99,7 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
             const int i = lane + 64 * m;
             if (i < N) yout[i] = 0;
         }
-        return;
+        return PvqBandCount{ N, 0, false };
     }
     const float b = __fdiv_rn((float)K, Sx);
     int sy = 0;
@@ -190,21 +225,36 @@ __device__ void pvq_search_wave(const float (&x)[M], int N, int K, PvqLds &L, in
                 if (lane + 64 * m == best) fy[m] = nf;
         }
     }
+    // per lane only the sum; non-zero pulses, the last of them and oversized ones through ballots (scalar work)
+    int tot = 0, nzc = 0, last = 0;
+    unsigned long long bigm = 0;
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const int i = lane + 64 * m;
-        if (i < N) {
-            const int iv = __float2int_rn(fy[m]);
-            yout[i] = (int16_t)(((neg >> m) & 1ull) ? -iv : iv);    // orps sign, cvtps2dq
-        }
+        const bool in = i < N;
+        const int iv = __float2int_rn(fy[m]);
+        if (in) yout[i] = (int16_t)(((neg >> m) & 1ull) ? -iv : iv);    // orps sign, cvtps2dq
+        const int a = in ? (iv < 0 ? -iv : iv) : 0;
+        tot += a;
+        const unsigned long long nzm = __ballot(a != 0);
+        nzc += (int)__popcll(nzm);
+        if (nzm) last = 64 * m + 64 - __clzll((long long)nzm);     // m ascends: the highest index so far
+        bigm |= __ballot(a >= K);
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    // The search leaves exactly K pulses (or none at all), so the coder stops behind the last non-zero one
+    // or never; more than K can only come out of the removal branch picking a pulse-free element, which it
+    // does not do as long as any p is positive -- counted from memory then, as the coder would.
+    if (tot > K) return pvq_count_from_memory(yout, N, K, lane);
+    return PvqBandCount{ tot == K ? last : N, nzc, bigm != 0 };
 }
 
 // bands in coding order (ffv2.c:100-120): band b = coefficients [1+BS[b], 1+BS[b+1])
 __device__ constexpr int PVQ_BS[14] = { 0, 15, 23, 31, 63, 95, 127, 255, 383, 511, 1023, 1535, 2047, 4096 };
 
 template <int M>
-__device__ __forceinline__ void quant_band(const int32_t *coef, int b, int32_t W, int K, PvqLds &L, int lane, int16_t *y)
+__device__ __forceinline__ PvqBandCount quant_band(const int32_t *coef, int b, int32_t W, int K, PvqLds &L, int lane, int16_t *y)
 {
     const int lo = 1 + PVQ_BS[b];
     const int N = PVQ_BS[b + 1] - PVQ_BS[b];                   // 2049 for the last band: it also
@@ -222,7 +272,7 @@ __device__ __forceinline__ void quant_band(const int32_t *coef, int b, int32_t W
     float x[M];
 #pragma unroll
     for (int m = 0; m < M; m++) x[m] = __fdiv_rn((float)cv[m], fgain);  // ffv2enc.c:169
-    pvq_search_wave<M>(x, N, K, L, lane, y + lo);
+    return pvq_search_wave<M>(x, N, K, L, lane, y + lo);
 }
 
 struct FFV2PvqArgs {
@@ -231,6 +281,13 @@ struct FFV2PvqArgs {
     int16_t *y;               // [nbp][FFV2_Y_STRIDE]; element 1+j of the coding order at y[1+j], W slot at y[4096]
     int qp;
     long long nbp;
+    // for the lane coder (null otherwise): what it will read of every band, so that no kernel has to walk
+    // the pulses again to find out
+    FFV2SymRec *cnt;          // [nbp] count[13], offset = their sum
+    uint32_t *bits;           // [nbp] raw bits of the block-plane: codes[14] (Exp-Golomb bits, T-stage) + sign bits
+    const uint32_t *codes;    // [nbp][FFV2_CODES_PER_BP]
+    int32_t *abort_;          // [nbp / nblk] |= 1: a pulse as large as the alphabet
+    int nblk;
 };
 
 __global__ __launch_bounds__(64, 3) void ffv2_pvq_kernel(const FFV2PvqArgs a)
@@ -241,10 +298,23 @@ __global__ __launch_bounds__(64, 3) void ffv2_pvq_kernel(const FFV2PvqArgs a)
     const int32_t *coef = a.coef + bp * 4096;
     const int32_t W = a.W ? a.W[bp] : 0;
     int16_t *y = a.y + bp * FFV2_Y_STRIDE;
-    for (int b = 0; b < 6; b++)  quant_band<1>(coef, b, W, a.qp, L, lane, y);
-    for (int b = 6; b < 9; b++)  quant_band<2>(coef, b, W, a.qp, L, lane, y);
-    for (int b = 9; b < 12; b++) quant_band<8>(coef, b, W, a.qp, L, lane, y);
-    quant_band<33>(coef, 12, W, a.qp, L, lane, y);
+    FFV2SymRec *r = a.cnt ? a.cnt + bp : nullptr;
+    uint32_t total = 0, nz = 0;
+    bool big = false;
+    auto note = [&](int b, const PvqBandCount c) {
+        if (r && lane == 0) r->count[b] = (uint16_t)c.stop;
+        total += (uint32_t)c.stop; nz += (uint32_t)c.nz; big = big || c.big;
+    };
+    for (int b = 0; b < 6; b++)  note(b, quant_band<1>(coef, b, W, a.qp, L, lane, y));
+    for (int b = 6; b < 9; b++)  note(b, quant_band<2>(coef, b, W, a.qp, L, lane, y));
+    for (int b = 9; b < 12; b++) note(b, quant_band<8>(coef, b, W, a.qp, L, lane, y));
+    note(12, quant_band<33>(coef, 12, W, a.qp, L, lane, y));
+    if (r && lane == 0) {
+        r->offset = total;
+        r->pad = 0;
+        a.bits[bp] = a.codes[bp * FFV2_CODES_PER_BP + 14] + nz;
+        if (big) atomicOr((int *)&a.abort_[bp / a.nblk], 1);
+    }
 }
 
 // test hook: the bare search on caller-provided float vectors
@@ -328,7 +398,18 @@ hipError_t ffv2_launch_compact(const int16_t *y, int qp, int nblk, int nframes, 
 
 hipError_t ffv2_launch_pvq(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, hipStream_t s)
 {
-    FFV2PvqArgs a{ coef, W, y, qp, nbp };
+    FFV2PvqArgs a{ coef, W, y, qp, nbp, nullptr, nullptr, nullptr, nullptr, 1 };
+    hipLaunchKernelGGL(ffv2_pvq_kernel, dim3((unsigned)nbp), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// The same, and for each block-plane what the lane coder's count pass would find (ffv2_lanecoder.hip):
+// cnt / bits / codes indexed like y (block-plane 0 = the launch's first), abort_ by frame (nblk block-planes each).
+hipError_t ffv2_launch_pvq_counted(const int32_t *coef, const int32_t *W, int16_t *y, int qp, long long nbp, int nblk,
+                                   const uint32_t *codes, FFV2SymRec *cnt, uint32_t *bits, int32_t *abort_, hipStream_t s)
+{
+    if (!codes || !cnt || !bits || !abort_ || nblk < 1) return hipErrorInvalidValue;
+    FFV2PvqArgs a{ coef, W, y, qp, nbp, cnt, bits, codes, abort_, nblk };
     hipLaunchKernelGGL(ffv2_pvq_kernel, dim3((unsigned)nbp), dim3(64), 0, s, a);
     return hipGetLastError();
 }

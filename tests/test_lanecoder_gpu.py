@@ -282,3 +282,33 @@ def test_lanecoder_windows_of_the_coding_order(oracle, window, fmt, P, H, W, dep
         enc.close()
     finally:
         lib.ffv2amd_debug_lanecoder_window(0)
+
+
+@pytest.mark.parametrize("fmt,P,H,W,depth,qp", [("yuv444p", 3, 100, 150, 8, 16), ("gray", 1, 130, 70, 8, 2),
+                                                ("yuv444p10le", 3, 64, 200, 10, 64), ("yuv444p12le", 3, 70, 70, 12, 7)])
+def test_lanecoder_counts_from_the_search_equal_the_count_pass(oracle, monkeypatch, fmt, P, H, W, depth, qp):
+    """Round 3: the PVQ search notes what the coder will read of each band (symbols until the magnitudes reach qp,
+    sign bits, a pulse as large as the alphabet -> abort) instead of a kernel walking the pulses again
+    (FFV2AMD_LC_COUNT_KERNEL=1 brings that pass back).  Same packets, same aborts, both equal to the oracle."""
+    enc = _enc(W, H, fmt, 2)
+    n = 6
+    frames = np.stack([synth.noise(17 * qp + i, P, H, W, depth) for i in range(n)])
+    frames[1, :, H // 2:, :] = (1 << (depth - 1)) + frames[1, :, H // 2:, :] % 3          # bands without a pulse
+    frames[2] = synth.make("S1", 2, P, H, W, depth)                                          # usually aborts
+    frames[4] = (1 << (depth - 1))                                                           # flat: nothing but zeros
+    frames[4, :, 3, 5] += 9
+    dev = enc.upload(frames)
+    enc.lanecoder_open(n)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FFV2AMD_LC_COUNT_KERNEL", mode)
+        pk, sizes, status = enc.lanecoder_encode(dev, qp, as_arrays=True)
+        got[mode] = [(int(status[i]), pk[i, : sizes[i]].tobytes() if status[i] == 0 else None) for i in range(n)]
+    assert got["0"] == got["1"]
+    for i in range(n):
+        try:
+            want = oracle.encode(frames[i], fmt, qp=qp)
+        except Exception:
+            want = None
+        assert got["0"][i] == ((0, want) if want is not None else (-1, None)), i
+    enc.close()

@@ -15,7 +15,7 @@ for sub in ("a", "b"):
     f = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "pvq_kernel" in row["Kernel_Name"]:
+        if "ffv2_pvq_" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for c, v in acc.items():
         v = v[-5:]

@@ -1523,6 +1523,7 @@ static uint32_t lanecoder_window(size_t maxsym16)
     const uint64_t least = ((uint64_t)maxsym16 / 4096 + 15) / 16 * 16;     // never more than ~4 096 windows (two launches each)
     if (w < least) w = least;
     if (w > maxsym16) w = maxsym16;
+    if (w > (1u << 22)) w = 1u << 22;                 // lc_cdf_kernel addresses a window's records of 64 frames with 32 bits (8 bytes each)
     return (uint32_t)w;
 }
 

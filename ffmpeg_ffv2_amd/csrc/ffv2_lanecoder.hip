@@ -52,12 +52,13 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long m)       // s
 }
 
 // Records in coding order, interleaved so that the chain kernel's loads coalesce: frames are
-// grouped `width` at a time (one lane each); symbol k of lane L sits in piece k/8 (64 bytes per
-// lane, pieces of all lanes side by side), slot k%8.
+// grouped `width` at a time (one lane each); symbol k of lane L sits in piece k/16 (a tile of the chain:
+// 128 bytes per lane = one cache line, so that the cdf kernel -- one wavefront per frame and row -- writes
+// whole lines; pieces of all lanes side by side), slot k%16.
 __device__ __forceinline__ uint2 *lc_record(uint2 *recs, size_t group_stride, int width, int f, uint32_t k)
 {
     const int g = f / width, L = f - g * width;
-    return recs + (size_t)g * group_stride + ((size_t)(k >> 3) * width + L) * 8 + (k & 7u);
+    return recs + (size_t)g * group_stride + ((size_t)(k >> 4) * width + L) * 16 + (k & 15u);
 }
 
 // Exp-Golomb code of ffv2enc.c:105-123 as the bits it appends (LSB first): for every bit of
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
         const uint32_t rb = rowbase[(size_t)b * (nb + 1) + bp];
         if (lane == 0) a.delta[((size_t)f * 13 + b) * nb + bp] = gb + before - rb;
         int len;
+#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 4)
+        len = 3; const unsigned long long code = 5;
+#else
         const unsigned long long code = golomb_code(cr[1 + b], &len);
+#endif
         put(code, len);
         uint8_t *dst = rows + rowoff + rb;
         // eight rows of 64 pulses at a time: their loads are in flight together (the kernel is the latency of its
@@ -209,14 +214,22 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
+#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 2)
+                qv[u] = (int)(j & 1u);
+#else
                 qv[u] = j < cntb ? yy[lo + j] : 0;
+#endif
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
                 if (j0 + 64u * (uint32_t)u >= cntb) break;
                 const int q = qv[u];
+#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 1)
+                if (j == 0xFFFFFFFFu) dst[j] = (uint8_t)(q < 0 ? -q : q);
+#else
                 if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
+#endif
                 const unsigned long long nzm = __ballot(q != 0);
                 if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
                 pos += (uint32_t)__popcll(nzm);
@@ -228,7 +241,11 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
     __syncthreads();
     {
         const uint32_t nwords = (pos + 31u) >> 5, w0 = bit0 >> 5;
+#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 8)
+        if ((uint32_t)lane < nwords && sink[lane] == 0x12345u && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
+#else
         if ((uint32_t)lane < nwords && sink[lane] && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
+#endif
     }
     if (lane == 0 && bp == 0) atomicOr(&raw[0], a.header_bits);
 }
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     const uint32_t w0 = a.win0, w1 = a.win1;
     auto put = [&](uint32_t gp, uint2 r) {
         const uint32_t k = gp - w0;
-        recs[((size_t)(k >> 3) * (size_t)a.width) * 8 + (k & 7u)] = r;
+        recs[((size_t)(k >> 4) * (size_t)a.width) * 16 + (k & 15u)] = r;
     };
     auto inwin = [&](uint32_t gp) { return gp >= w0 && gp < w1; };
     // the row as the previous window left it: entries, total, position, block-plane
@@ -287,107 +304,153 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         R = st[lane]; F0 = st[64]; bp_cur = st[66];
     }
     uint32_t seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;     // end of the current block-plane's band in this row
-    uint32_t dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;                      // ... and its delta
+    uint32_t dl_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u));   // ... and its delta
     bool halve = false;
     uint32_t m = k0 < L ? chunk_len(F0, k0, &halve) : 0u;
     // symbols are loaded unconditionally (address clamped to the row) and masked when used: a
     // load under a lane mask makes the compiler wait for it on the spot
     const uint32_t last = L ? L - 1u : 0u;
-    const uint32_t p0 = k0 + (uint32_t)lane;
-    uint32_t xr = src[p0 < last ? p0 : last];
-    while (k0 < L) {
-        // the next chunk's symbols are on their way while this one is worked on
-        uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
-        uint32_t k1 = k0 + m;
-        bool halve1 = false;
-        const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
-        const uint32_t p1 = k1 + (uint32_t)lane;
-        const uint32_t xr1 = src[p1 < last ? p1 : last];
-
-        // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
-        // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
-        // prefix count over them gives every lane its block-plane.
-        uint32_t dl, rel = 0xFFFFFFFFu;
-        const bool inside = seg_end - k0 >= m && seg_end - k0 > 0u;
-        if (inside) {
-            dl = dl_cur;
-        } else {
-            const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
-            const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
-            rel = idx <= (uint32_t)nb ? rb - k0 : 0xFFFFFFFFu;         // > 0: bp_cur holds symbol k0
-            flag[lane] = 0;
-            if (lane < 2) flag[64 + lane] = 0;
-            __syncthreads();
-            if (rel <= 64u) flag[rel] = 1;
-            __syncthreads();
-            const uint32_t mine = flag[lane];
-            const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
-            dl = delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
-        }
-        // the window ends inside this chunk (coding-order positions grow with the lane): cut it there
-        const uint32_t gp = k0 + (uint32_t)lane + dl;
-        const unsigned long long over = __ballot((uint32_t)lane < m && gp >= w1);
-        bool last_chunk = false;
-        if (over) {
-            const uint32_t mc = (uint32_t)__ffsll((long long)over) - 1u;
-            if (mc == 0u) break;                                       // nothing of this chunk belongs to the window
-            m = mc; halve = false; last_chunk = true;
-            F1 = F0 + 64u * m; k1 = k0 + m;
-        }
-        const uint32_t x = (uint32_t)lane < m ? xr : 255u;
-
-        // prefix counts: cl / ch = symbols of this chunk in front of lane t with a value below / up
-        // to lane t's own; ca (lane i as row entry i) = symbols of the chunk with value <= i.  One
-        // round per DISTINCT value in the chunk (a band's pulses are mostly 0 and 1), not per value.
-        uint32_t cl = 0, ch = 0, ca = 0;
-        unsigned long long rem = __ballot(x < 255u);
-        while (rem) {
-            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)x, __ffsll((long long)rem) - 1);
-            const unsigned long long mk = __ballot(x == v);
-            const uint32_t e = lane_prefix(mk);
-            if (v < x) cl += e;
-            if (v <= x) ch += e;
-            if (v <= (uint32_t)lane) ca += (uint32_t)__popcll(mk);
-            rem &= ~mk;
-        }
-        const uint32_t Rlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1u) << 2), (int)R);
-        const uint32_t Rhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(x << 2), (int)R);
-        uint32_t fl = x ? Rlo + 64u * cl : 0u, fh = Rhi + 64u * ch, ft = F0 + 64u * (uint32_t)lane;
-        const int sc = __clz(ft - 1u) - 17;                          // 15 - ilog(ft - 1), daala_entropy.c:346
-        fl <<= sc; fh <<= sc; ft <<= sc;
-
-        // the block-plane the row stands in after this chunk
-        if (inside) {
-            if (seg_end - k0 == m) {                                   // the band ends with this chunk
-                bp_cur++;
-                seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
-                dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
-            }
-        } else {
-            bp_cur += (uint32_t)__popcll(__ballot(rel <= m));
-            seg_end = bp_cur < (uint32_t)nb ? rowbase[bp_cur + 1u] : 0xFFFFFFFFu;
-            dl_cur = bp_cur < (uint32_t)nb ? delta[bp_cur] : 0u;
-        }
-        if ((uint32_t)lane < m) {
-            if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by lc_count_kernel already
-            else {
-#if defined(LC_CDF_EXP) && LC_CDF_EXP == 1    // timing experiment: no record stores
-                if (gp == 0xFFFFFFFFu) put(gp, make_uint2(fl | (fh << 16), ft));
-#else
-                put(gp, make_uint2(fl | (fh << 16), ft));
-#endif
-            }
-        }
-
-        // the row after this chunk (daala_entropy.c:434-439)
-        const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)m - 1);
-        const uint32_t ge = lastx <= (uint32_t)lane ? 1u : 0u;
-        if (halve) R = ((R + 64u * (ca - ge)) >> 1) + (uint32_t)lane + 1u + 64u * ge;
-        else R += 64u * ca;
-        F0 = F1; k0 = k1;
-        if (last_chunk) break;
-        m = m1; halve = halve1; xr = xr1;
+    auto fetch = [&](uint32_t k) { const uint32_t p = k + (uint32_t)lane; return (uint32_t)src[p < last ? p : last]; };
+    // Memory waits.  Loads and stores share one counter on this chip and return out of order with respect to each
+    // other, so every wait the compiler inserts is for ALL of them: one chunk at a time the kernel ran at the latency
+    // of each chunk's own record store (and of its symbols, asked for one chunk ahead).  Hence groups of LC_GROUP
+    // chunks: where the chunks start depends on the symbol count alone, so at the top of a group the symbols of the
+    // NEXT group are asked for and the records of the PREVIOUS group (kept in registers) are sent; the one wait per
+    // group, where the next group's symbols change registers, then finds everything a whole group old.
+    constexpr int LC_GROUP = 4;
+    constexpr uint32_t NOREC = 0xFFFFFFFFu;
+    auto next_chunk = [&](uint32_t Fp, uint32_t kp, uint32_t mp, bool hp, uint32_t *F, uint32_t *k, uint32_t *mm, bool *h) {
+        *F = hp ? ((Fp + 64u * (mp - 1u)) >> 1) + (uint32_t)n + 64u : Fp + 64u * mp;
+        *k = kp + mp;
+        *h = false;
+        *mm = *k < L ? chunk_len(*F, *k, h) : 0u;
+    };
+    uint32_t gF = F0, gk = k0, gm = m;           // the next chunk to ask for (wave-uniform, runs ahead of F0 / k0 / m)
+    bool gh = halve;
+    uint32_t xcur[LC_GROUP], xnext[LC_GROUP];
+#pragma unroll
+    for (int j = 0; j < LC_GROUP; j++) {
+        xcur[j] = fetch(gk);
+        next_chunk(gF, gk, gm, gh, &gF, &gk, &gm, &gh);
     }
+    uint2 prec[LC_GROUP], crec[LC_GROUP];        // records of the previous / this group and where they go (byte offset, NOREC: nowhere)
+    uint32_t poff[LC_GROUP], coff[LC_GROUP];
+#pragma unroll
+    for (int j = 0; j < LC_GROUP; j++) { poff[j] = NOREC; prec[j] = make_uint2(0u, 0u); }
+    auto send = [&](uint32_t off, uint2 r) {
+        if (off != NOREC) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(recs) + off) = r;
+    };
+    bool done = false;
+    while (!done && k0 < L) {
+#pragma unroll
+        for (int j = 0; j < LC_GROUP; j++) send(poff[j], prec[j]);
+#pragma unroll
+        for (int j = 0; j < LC_GROUP; j++) {
+            xnext[j] = fetch(gk);
+            next_chunk(gF, gk, gm, gh, &gF, &gk, &gm, &gh);
+            coff[j] = NOREC; crec[j] = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < LC_GROUP; j++) {
+            if (!(k0 < L)) { done = true; break; }
+            uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
+            uint32_t k1 = k0 + m;
+            bool halve1 = false;
+            const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
+
+            // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
+            // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
+            // prefix count over them gives every lane its block-plane.
+            uint32_t dl, rel = 0xFFFFFFFFu;
+            const bool inside = seg_end - k0 >= m && seg_end - k0 > 0u;
+            if (inside) {
+                dl = dl_cur;
+            } else {
+                const uint32_t idx = bp_cur + 1u + (uint32_t)lane;
+                const uint32_t rb = idx <= (uint32_t)nb ? rowbase[idx] : 0xFFFFFFFFu;
+                rel = idx <= (uint32_t)nb ? rb - k0 : 0xFFFFFFFFu;         // > 0: bp_cur holds symbol k0
+                flag[lane] = 0;
+                if (lane < 2) flag[64 + lane] = 0;
+                __syncthreads();
+                if (rel <= 64u) flag[rel] = 1;
+                __syncthreads();
+                const uint32_t mine = flag[lane];
+                const uint32_t seg = bp_cur + lane_prefix(__ballot(mine != 0)) + mine;
+                dl = delta[seg < (uint32_t)nb ? seg : (uint32_t)nb - 1u];
+            }
+            // the window ends inside this chunk (coding-order positions grow with the lane): cut it there
+            const uint32_t gp = k0 + (uint32_t)lane + dl;
+            const unsigned long long over = __ballot((uint32_t)lane < m && gp >= w1);
+            bool last_chunk = false;
+            if (over) {
+                const uint32_t mc = (uint32_t)__ffsll((long long)over) - 1u;
+                if (mc == 0u) { done = true; break; }                      // nothing of this chunk belongs to the window
+                m = mc; halve = false; last_chunk = true;
+                F1 = F0 + 64u * m; k1 = k0 + m;
+            }
+            const uint32_t x = (uint32_t)lane < m ? xcur[j] : 255u;
+
+            // prefix counts: cl / ch = symbols of this chunk in front of lane t with a value below / up
+            // to lane t's own; ca (lane i as row entry i) = symbols of the chunk with value <= i.  One
+            // round per DISTINCT value in the chunk (a band's pulses are mostly 0 and 1), not per value.
+            uint32_t cl = 0, ch = 0, ca = 0;
+            unsigned long long rem = __ballot(x < 255u);
+            while (rem) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)x, __ffsll((long long)rem) - 1);
+                const unsigned long long mk = __ballot(x == v);
+                const uint32_t e = lane_prefix(mk);
+                if (v < x) cl += e;
+                if (v <= x) ch += e;
+                if (v <= (uint32_t)lane) ca += (uint32_t)__popcll(mk);
+                rem &= ~mk;
+            }
+            const uint32_t Rlo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((x - 1u) << 2), (int)R);
+            const uint32_t Rhi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(x << 2), (int)R);
+            uint32_t fl = x ? Rlo + 64u * cl : 0u, fh = Rhi + 64u * ch, ft = F0 + 64u * (uint32_t)lane;
+            const int sc = __clz(ft - 1u) - 17;                          // 15 - ilog(ft - 1), daala_entropy.c:346
+            fl <<= sc; fh <<= sc; ft <<= sc;
+
+            // the block-plane the row stands in after this chunk
+            if (inside) {
+                if (seg_end - k0 == m) {                                   // the band ends with this chunk
+                    bp_cur++;
+                    // (wave-uniform, kept in scalar registers: the wait for them is here, once per band, not at
+                    // their use in every chunk)
+                    const uint32_t bq = bp_cur < (uint32_t)nb ? bp_cur : (uint32_t)nb - 1u;
+                    const uint32_t t0 = rowbase[bq + 1u], t1 = delta[bq];          // both on their way, one wait
+                    seg_end = bp_cur < (uint32_t)nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)t0) : 0xFFFFFFFFu;
+                    dl_cur = bp_cur < (uint32_t)nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)t1) : 0u;
+                }
+            } else {
+                bp_cur += (uint32_t)__popcll(__ballot(rel <= m));
+                const uint32_t bq = bp_cur < (uint32_t)nb ? bp_cur : (uint32_t)nb - 1u;
+                const uint32_t t0 = rowbase[bq + 1u], t1 = delta[bq];
+                seg_end = bp_cur < (uint32_t)nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)t0) : 0xFFFFFFFFu;
+                dl_cur = bp_cur < (uint32_t)nb ? (uint32_t)__builtin_amdgcn_readfirstlane((int)t1) : 0u;
+            }
+            if ((uint32_t)lane < m) {
+                if (x >= (uint32_t)n) atomicOr((int *)&a.abort_[f], 1);       // counted out by the search already
+                else {
+                    const uint32_t kk = gp - w0;                           // < 2^18 * ...: the offset fits 32 bits (a window's records are < 4 GB)
+                    coff[j] = (((kk >> 4) * (uint32_t)a.width) * 16u + (kk & 15u)) * 8u;
+                    crec[j] = make_uint2(fl | (fh << 16), ft);
+                }
+            }
+
+            // the row after this chunk (daala_entropy.c:434-439)
+            const uint32_t lastx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)m - 1);
+            const uint32_t ge = lastx <= (uint32_t)lane ? 1u : 0u;
+            if (halve) R = ((R + 64u * (ca - ge)) >> 1) + (uint32_t)lane + 1u + 64u * ge;
+            else R += 64u * ca;
+            F0 = F1; k0 = k1;
+            if (last_chunk) { done = true; break; }
+            m = m1; halve = halve1;
+        }
+#pragma unroll
+        for (int j = 0; j < LC_GROUP; j++) { xcur[j] = xnext[j]; poff[j] = coff[j]; prec[j] = crec[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < LC_GROUP; j++) send(poff[j], prec[j]);
     // the row as it stands, for the next window
     st[lane] = R;
     if (lane == 0) { st[64] = F0; st[65] = k0; st[66] = bp_cur; }
@@ -498,8 +561,8 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
     if (role == 0) {
         // ---- the recurrence ----
         const uint4 *base = reinterpret_cast<const uint4 *>(a.recs + (size_t)a.win_buf * a.buf_stride + (size_t)g * a.group_stride)
-                            + (size_t)(live ? lane : 0) * 4;
-        const size_t piece = (size_t)a.width * 4;                      // uint4 per piece row (64 bytes per lane)
+                            + (size_t)(live ? lane : 0) * 8;
+        const size_t piece = (size_t)a.width * 8;                      // uint4 per row of pieces (a tile: 128 bytes per lane)
         uint32_t rng = st0.rng;
         // records two tiles ahead of the one being worked on (a tile is ~2 500 cycles of recurrence)
         uint4 buf[3][8];
@@ -507,7 +570,7 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
         for (int p = 0; p < 2; p++) {
             if ((uint32_t)p < ntiles) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) buf[p][i] = base[((size_t)p * 2 + (i >> 2)) * piece + (i & 3)];
+                for (int i = 0; i < 8; i++) buf[p][i] = base[(size_t)p * piece + i];
             }
         }
         for (uint32_t t = 0; t < maxt; t += 3) {
@@ -517,7 +580,7 @@ __global__ __launch_bounds__(128) void lc_chain_kernel(const FFV2LaneCoderArgs a
                 if (tt >= maxt) break;
                 if (tt + 2 < ntiles) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) buf[(h + 2) % 3][i] = base[((size_t)(tt + 2) * 2 + (i >> 2)) * piece + (i & 3)];
+                    for (int i = 0; i < 8; i++) buf[(h + 2) % 3][i] = base[(size_t)(tt + 2) * piece + i];
                 }
                 while (tt - peek(&consumed) >= (uint32_t)LC_RING) __builtin_amdgcn_s_sleep(2);      // ring full
                 asm volatile("" ::: "memory");

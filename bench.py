@@ -225,6 +225,14 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                                        "(upper bound: every pulse searched); peak = f32 VALU lanes x 2.4 GHz / 11" % nq}
         except Exception as ex:
             res["roofline"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        if world == 1 and not args.no_host_boundary:
+            # the same qp with the frames in HOST memory and the packets back in host memory, through the qp > 0 ring
+            # (ffv2amd_qpring_*: what send_frame / receive_packet reach with qp_frames_per_call set)
+            try:
+                first = buf[int(offs[0]): int(offs[0]) + int(sizes[0])].tobytes()
+                res["host_boundary"] = qp_host_boundary(args, enc, host_frames, F, first)
+            except Exception as ex:
+                res["host_boundary"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_cpu_baseline:
             from tests import oracle_lib
             oracle = oracle_lib.load()
@@ -248,6 +256,60 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def qp_host_boundary(args, enc, host_frames, F, packet0):
+    """Frames in host memory -> ffv2amd_qpring_send / _receive -> packets in host memory at qp > 0: batches of
+    frames coded side by side on the device, two batches in flight.  Returns the host_boundary block."""
+    enc.lanecoder_close()
+    i = enc.info
+    W, H = i.width, i.height
+    per_call = max(64, min(F // 2, 2048) // 64 * 64)
+    total = 4 * per_call
+    nsrc = host_frames.shape[0]
+    out = {"frames_per_call": per_call, "frames_sent": total, "what":
+           "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
+           "flight) -> ffv2amd_qpring_receive: packets in host memory in send order; pinned: page-locked frames read in "
+           "place; pageable: rows copied by the calling thread into page-locked bounce frames; yuv420: the literal 4:2:0 "
+           "frames, up-converted on the device"}
+    y420 = [yuv420_of(f) for f in host_frames] if i.planes == 3 else None
+    for name, pinned, is420 in [("pinned", True, False), ("pageable", False, False), ("yuv420_pinned", True, True)]:
+        if is420 and y420 is None:
+            continue
+        if pinned and not is420:
+            src = enc.pinned_frames(nsrc)
+            src[:] = host_frames
+            src = [src[n] for n in range(nsrc)]
+        elif pinned:
+            pool = enc.pinned_frames_420(nsrc)
+            for dst, planes in zip(pool, y420):
+                for d, a in zip(dst, planes):
+                    d[:] = a
+            src = pool
+        else:
+            src = [host_frames[n] for n in range(nsrc)]
+        enc.qpring_open(args.qp, per_call, args.packet_cap)
+        got, sent, first, flushed = 0, 0, None, False
+        t0 = time.perf_counter()
+        while got < total:
+            while sent < total and enc.qpring_send(src[sent % nsrc], tag=sent, pinned=pinned, yuv420=is420):
+                sent += 1
+            if sent == total and not flushed:
+                flushed = enc.qpring_flush()
+            r = enc.qpring_receive(wait=True)
+            if r is None:
+                continue
+            assert r[0] == got, "qp ring delivered out of order"
+            if got == 0:
+                first = r[1]
+            got += 1
+        dt = time.perf_counter() - t0
+        enc.qpring_close()
+        enc.free_pinned()
+        out[name] = {"Mpix_s": round(total * W * H / dt / 1e6, 1), "ms_per_frame": round(dt / total * 1e3, 4)}
+        if not is420:
+            out[name]["packet0_equals_device_path"] = bool(first == packet0)
+    return out
 
 
 def spawn_ranks(n):

@@ -20,6 +20,7 @@ EXPORTS = [
     "ffv2amd_ring_open", "ffv2amd_ring_send", "ffv2amd_ring_receive", "ffv2amd_ring_pending", "ffv2amd_ring_close",
     "ffv2amd_host_alloc", "ffv2amd_host_free", "ffv2amd_qp_submit", "ffv2amd_qp_finish",
     "ffv2amd_ring_send_420", "ffv2amd_tstage_wide_device", "ffv2amd_decode_frame", "ffv2amd_parse_packet", "ffv2amd_qp_send_frame", "ffv2amd_qp_send_frame_420", "ffv2amd_qp_receive_packet", "ffv2amd_qp_pending", "ffv2amd_encoder_set_device_coder",
+    "ffv2amd_qpring_open", "ffv2amd_qpring_send", "ffv2amd_qpring_flush", "ffv2amd_qpring_receive", "ffv2amd_qpring_pending", "ffv2amd_qpring_close",
     "ffv2amd_frame_bytes_420", "ffv2amd_upconvert_420_device", "ffv2amd_encode_frame_420",
     "ffv2amd_lanecoder_open", "ffv2amd_lanecoder_close", "ffv2amd_lanecoder_bytes_per_frame", "ffv2amd_lanecoder_encode",
     "ffv2amd_lanecoder_submit", "ffv2amd_lanecoder_finish", "ffv2amd_lanecoder_finish_packed", "ffv2amd_lanecoder_stats", "ffv2amd_debug_lanecoder_window", "ffv2amd_debug_pvq_time",
@@ -110,6 +111,12 @@ def load():
     lib.ffv2amd_qp_send_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.c_int, C.c_void_p, C.c_int64]
     lib.ffv2amd_qp_receive_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]
     lib.ffv2amd_qp_pending.argtypes = [C.c_void_p]
+    lib.ffv2amd_qpring_open.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+    lib.ffv2amd_qpring_send.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.c_void_p, C.c_int64, C.c_uint]
+    lib.ffv2amd_qpring_flush.argtypes = [C.c_void_p]
+    lib.ffv2amd_qpring_receive.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int64), C.c_int]
+    lib.ffv2amd_qpring_pending.argtypes = [C.c_void_p]
+    lib.ffv2amd_qpring_close.argtypes = [C.c_void_p]
     lib.ffv2amd_ring_pending.argtypes = [C.c_void_p]
     lib.ffv2amd_ring_close.argtypes = [C.c_void_p]
     lib.ffv2amd_ring_close.restype = None

@@ -722,6 +722,38 @@ struct ffv2amd_encoder {
         uint32_t last_symbols0 = 0;
         std::vector<void *> allocs;      // every device buffer above, for close
     } lc;
+    // send_frame / receive_packet at qp > 0 on top of the lane coder (ffv2amd_qpring_*): frames are collected a batch
+    // at a time in device memory, every full batch is one lane coder call, packets come back in send order
+    struct QpRing {
+        int qp = 0, cap = 0;                     // frames per batch (= per lane coder call)
+        size_t pcap = 0;
+        uint8_t *d_frames[3] = { nullptr, nullptr, nullptr };     // a batch being filled + two in flight
+        uint8_t *d_c420[3] = { nullptr, nullptr, nullptr };      // 4:2:0 chroma as it arrives: [cap][U plane, V plane]
+        int32_t *d_w[3] = { nullptr, nullptr, nullptr };
+        bool any_w[3] = { false, false, false };
+        std::vector<int64_t> tags[3];
+        int fill = 0, count = 0;                 // buffer being filled, frames in it
+        int flight[2] = { -1, -1 };              // buffers of the calls in flight, oldest first
+        int flight_n[2] = { 0, 0 };
+        int nflight = 0;
+        hipStream_t h2d = nullptr;
+        hipEvent_t ev_batch = nullptr;
+        // page-locked bounce frames for pageable callers
+        static constexpr int NBOUNCE = 4;
+        uint8_t *bounce[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
+        int32_t *bounce_w[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
+        hipEvent_t ev_bounce[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
+        unsigned nb_seq = 0;
+        // the batch finished last, waiting to be received
+        uint8_t *h_buf = nullptr;
+        size_t h_cap = 0;
+        std::vector<uint64_t> offs;
+        std::vector<uint32_t> sizes;
+        std::vector<int32_t> status;
+        std::vector<int64_t> done_tags;
+        int done_n = 0, done_at = 0;
+        bool open = false;
+    } qr;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -808,6 +840,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     if (!e) return;
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    ffv2amd_qpring_close(e);
     ffv2amd_ring_close(e);
     ffv2_upconv_destroy(e->upconv);
     (void)hipFree(e->d_420);
@@ -2190,6 +2223,254 @@ int ffv2amd_qp_receive_packet(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, 
     if (r < 0) return r;
     if (st < 0) return st;                                       // the frame has left the pipeline all the same
     *out_size = sz;
+    return FFV2AMD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// send_frame / receive_packet at qp > 0 at the device coder's rate (encode.c:420,449 around ffv2enc.c:453).
+// The adaptive range coder is one chain per frame, so frames are coded many at a time (ffv2_lanecoder.hip):
+// this ring collects them `frames_per_call` at a time in device memory as they arrive (H2D on its own stream),
+// hands every full batch to the lane coder (two calls in flight) and gives the packets back in send order.
+// ---------------------------------------------------------------------------------------------
+int ffv2amd_qpring_close(ffv2amd_encoder *e)
+{
+    if (!e) return FFV2AMD_ERR_INVAL;
+    auto &r = e->qr;
+    if (!r.open && !r.h2d) return FFV2AMD_OK;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    if (r.h2d) (void)hipStreamSynchronize(r.h2d);
+    (void)hipStreamSynchronize(e->stream);
+    (void)ffv2amd_lanecoder_close(e);
+    for (int i = 0; i < 3; i++) {
+        (void)hipFree(r.d_frames[i]); (void)hipFree(r.d_c420[i]); (void)hipFree(r.d_w[i]);
+        r.d_frames[i] = nullptr; r.d_c420[i] = nullptr; r.d_w[i] = nullptr; r.any_w[i] = false; r.tags[i].clear();
+    }
+    for (int i = 0; i < ffv2amd_encoder::QpRing::NBOUNCE; i++) {
+        if (r.bounce[i]) (void)hipHostFree(r.bounce[i]);
+        if (r.bounce_w[i]) (void)hipHostFree(r.bounce_w[i]);
+        if (r.ev_bounce[i]) (void)hipEventDestroy(r.ev_bounce[i]);
+        r.bounce[i] = nullptr; r.bounce_w[i] = nullptr; r.ev_bounce[i] = nullptr;
+    }
+    if (r.h_buf) (void)hipHostFree(r.h_buf);
+    r.h_buf = nullptr; r.h_cap = 0;
+    if (r.ev_batch) (void)hipEventDestroy(r.ev_batch);
+    if (r.h2d) (void)hipStreamDestroy(r.h2d);
+    r.ev_batch = nullptr; r.h2d = nullptr;
+    r.fill = r.count = r.nflight = r.done_n = r.done_at = 0;
+    r.open = false;
+    (void)hipGetLastError();
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qpring_open(ffv2amd_encoder *e, int qp, int frames_per_call, size_t packet_cap)
+{
+    if (!e || frames_per_call < 1) return FFV2AMD_ERR_INVAL;
+    if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
+    if (e->qr.open) return FFV2AMD_ERR_INVAL;
+    if (e->lc.cap) return FFV2AMD_ERR_INVAL;                     // the lane coder is in use by its own entry points
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    const ffv2amd_info &in = e->info;
+    auto &r = e->qr;
+    int rc = ffv2amd_lanecoder_open(e, frames_per_call, packet_cap, 2);
+    if (rc < 0) return rc;
+    r.qp = qp; r.cap = frames_per_call;
+    r.pcap = packet_cap ? packet_cap : in.packet_cap_qp;
+#define QK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; } } while (0)
+    QK(hipStreamCreateWithFlags(&r.h2d, hipStreamNonBlocking));
+    QK(hipEventCreateWithFlags(&r.ev_batch, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) {
+        QK(hipMalloc(&r.d_frames[i], in.frame_stride * (size_t)frames_per_call));
+        try { r.tags[i].assign((size_t)frames_per_call, 0); } catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
+    }
+    r.h_cap = (size_t)frames_per_call * (r.pcap + 16);
+    QK(hipHostMalloc(&r.h_buf, r.h_cap, hipHostMallocDefault));
+#undef QK
+    try {
+        r.offs.assign((size_t)frames_per_call + 1, 0); r.sizes.assign((size_t)frames_per_call, 0);
+        r.status.assign((size_t)frames_per_call, 0); r.done_tags.assign((size_t)frames_per_call, 0);
+    } catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
+    r.fill = 0; r.count = 0; r.nflight = 0; r.done_n = r.done_at = 0;
+    r.open = true;
+    return FFV2AMD_OK;
+}
+
+// the oldest call in flight -> the packets waiting to be received (blocks until that call is through)
+static int qpring_collect(ffv2amd_encoder *e)
+{
+    auto &r = e->qr;
+    if (r.nflight == 0) return FFV2AMD_ERR_AGAIN;
+    if (r.done_at < r.done_n) return FFV2AMD_ERR_AGAIN;          // the previous batch has not been received yet
+    const int b = r.flight[0], n = r.flight_n[0];
+    const int rc = ffv2amd_lanecoder_finish_packed(e, r.h_buf, r.h_cap, r.offs.data(), r.sizes.data(), r.status.data());
+    if (rc < 0) return rc;
+    for (int i = 0; i < n; i++) r.done_tags[(size_t)i] = r.tags[b][(size_t)i];
+    r.done_n = n; r.done_at = 0;
+    r.flight[0] = r.flight[1]; r.flight_n[0] = r.flight_n[1]; r.nflight--;
+    return FFV2AMD_OK;
+}
+
+// the batch being filled -> the lane coder.  FFV2AMD_ERR_AGAIN: two calls are in flight and the one before them has
+// not been received yet (the caller has to take packets first).
+static int qpring_submit(ffv2amd_encoder *e)
+{
+    auto &r = e->qr;
+    if (r.count == 0) return FFV2AMD_OK;
+    if (r.nflight == 2) {
+        const int rc = qpring_collect(e);
+        if (rc < 0) return rc;
+    }
+    HIPCHK(hipEventRecord(r.ev_batch, r.h2d));
+    HIPCHK(hipStreamWaitEvent(e->stream, r.ev_batch, 0));
+    const int b = r.fill;
+    const int rc = ffv2amd_lanecoder_submit(e, r.count, r.d_frames[b], r.qp, r.any_w[b] ? r.d_w[b] : nullptr);
+    if (rc < 0) return rc;
+    r.flight[r.nflight] = b; r.flight_n[r.nflight] = r.count; r.nflight++;
+    // the next batch goes into the buffer no call in flight reads
+    for (int i = 0; i < 3; i++) {
+        bool used = false;
+        for (int k = 0; k < r.nflight; k++) used = used || r.flight[k] == i;
+        if (!used) { r.fill = i; break; }
+    }
+    r.count = 0;
+    r.any_w[r.fill] = false;
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qpring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                        const int32_t *W, int64_t tag, unsigned flags)
+{
+    if (!e || !data || !linesize) return FFV2AMD_ERR_INVAL;
+    auto &r = e->qr;
+    if (!r.open) return FFV2AMD_ERR_INVAL;
+    const ffv2amd_info &in = e->info;
+    const bool is420 = (flags & FFV2AMD_FRAME_YUV420) != 0;
+    const int npl = is420 ? 3 : in.planes;
+    if (is420 && in.planes != 3) return FFV2AMD_ERR_INVAL;
+    for (int p = 0; p < npl; p++)
+        if (!data[p]) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    if (r.count == r.cap) {                                      // a full batch that could not leave yet
+        const int rc = qpring_submit(e);
+        if (rc < 0) return rc;
+    }
+    const int b = r.fill;
+    const size_t bps = in.depth > 8 ? 2 : 1, nb = (size_t)in.block_planes;
+    const int cw = (in.width + 1) >> 1, ch = (in.height + 1) >> 1;
+    const size_t c_pitch = align_up((size_t)cw * bps, 128);
+    if (is420) {
+        int rc = upconv_ready(e);
+        if (rc < 0) return rc;
+        if (!r.d_c420[b]) HIPCHK(hipMalloc(&r.d_c420[b], 2 * c_pitch * (size_t)ch * (size_t)r.cap));
+    }
+    uint8_t *d_frame = r.d_frames[b] + (size_t)r.count * in.frame_stride;
+    uint8_t *d_c = is420 ? r.d_c420[b] + (size_t)r.count * 2 * c_pitch * (size_t)ch : nullptr;
+    // where each plane goes: rows `pitch` apart on the device
+    struct Pl { const uint8_t *src; ptrdiff_t ls; size_t row_bytes, pitch; int rows; uint8_t *dst; } pl[4];
+    for (int p = 0; p < npl; p++) {
+        const bool chroma = is420 && p > 0;
+        pl[p].src = data[p]; pl[p].ls = linesize[p];
+        pl[p].row_bytes = (size_t)(chroma ? cw : in.width) * bps;
+        pl[p].pitch = chroma ? c_pitch : in.row_pitch;
+        pl[p].rows = chroma ? ch : in.height;
+        pl[p].dst = chroma ? d_c + (size_t)(p - 1) * c_pitch * (size_t)ch : d_frame + (size_t)(is420 ? 0 : p) * in.plane_stride;
+    }
+    hipStream_t sh = r.h2d;
+    if (flags & FFV2AMD_FRAME_PINNED) {
+        for (int p = 0; p < npl; p++) {
+            if (pl[p].ls == (ptrdiff_t)pl[p].pitch)
+                HIPCHK(hipMemcpyAsync(pl[p].dst, pl[p].src, pl[p].pitch * (size_t)(pl[p].rows - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh));
+            else
+                HIPCHK(hipMemcpy2DAsync(pl[p].dst, pl[p].pitch, pl[p].src, (size_t)pl[p].ls, pl[p].row_bytes, (size_t)pl[p].rows, hipMemcpyHostToDevice, sh));
+        }
+    } else {
+        // pageable memory: through one of a few page-locked frames (complete when the call returns as far as the caller
+        // is concerned: its rows are copied here)
+        const int k = (int)(r.nb_seq++ % (unsigned)ffv2amd_encoder::QpRing::NBOUNCE);
+        if (!r.bounce[k]) {
+            HIPCHK(hipHostMalloc(&r.bounce[k], in.frame_stride, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&r.ev_bounce[k], hipEventDisableTiming));
+        } else {
+            HIPCHK(hipEventSynchronize(r.ev_bounce[k]));
+        }
+        uint8_t *at = r.bounce[k];
+        for (int p = 0; p < npl; p++) {
+            for (int y = 0; y < pl[p].rows; y++)
+                memcpy(at + (size_t)y * pl[p].pitch, pl[p].src + (ptrdiff_t)y * pl[p].ls, pl[p].row_bytes);
+            HIPCHK(hipMemcpyAsync(pl[p].dst, at, pl[p].pitch * (size_t)(pl[p].rows - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh));
+            at += pl[p].pitch * (size_t)pl[p].rows;
+        }
+        HIPCHK(hipEventRecord(r.ev_bounce[k], sh));
+    }
+    if (is420)
+        HIPCHK(ffv2_launch_upconv_chroma(e->upconv, e->geom, 1, d_c, c_pitch, c_pitch * (size_t)ch, 0, d_frame, sh));
+    if (W) {
+        if (!r.d_w[b]) HIPCHK(hipMalloc(&r.d_w[b], sizeof(int32_t) * nb * (size_t)r.cap));
+        if (!r.any_w[b]) {
+            HIPCHK(hipMemsetAsync(r.d_w[b], 0, sizeof(int32_t) * nb * (size_t)r.cap, sh));
+            r.any_w[b] = true;
+        }
+        // W may be pageable and reused by the caller: the copy is complete when the call returns
+        HIPCHK(hipMemcpyAsync(r.d_w[b] + (size_t)r.count * nb, W, sizeof(int32_t) * nb, hipMemcpyHostToDevice, sh));
+        HIPCHK(hipStreamSynchronize(sh));
+    }
+    r.tags[b][(size_t)r.count] = tag;
+    r.count++;
+    if (r.count == r.cap) {
+        const int rc = qpring_submit(e);                         // AGAIN here is not the caller's: the frame is in
+        if (rc < 0 && rc != FFV2AMD_ERR_AGAIN) return rc;
+    }
+    return FFV2AMD_OK;
+}
+
+int ffv2amd_qpring_flush(ffv2amd_encoder *e)
+{
+    if (!e || !e->qr.open) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    return qpring_submit(e);
+}
+
+int ffv2amd_qpring_pending(const ffv2amd_encoder *e)
+{
+    if (!e || !e->qr.open) return 0;
+    const auto &r = e->qr;
+    int n = r.count + (r.done_n - r.done_at);
+    for (int k = 0; k < r.nflight; k++) n += r.flight_n[k];
+    return n;
+}
+
+int ffv2amd_qpring_receive(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag, int wait)
+{
+    if (!e || !out || !out_size) return FFV2AMD_ERR_INVAL;
+    auto &r = e->qr;
+    if (!r.open) return FFV2AMD_ERR_INVAL;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return FFV2AMD_ERR_DEVICE;
+    if (r.done_at == r.done_n) {
+        if (r.nflight == 0) return FFV2AMD_ERR_AGAIN;            // nothing submitted: send more frames, or flush
+        if (!wait) {
+            auto &q = e->lc.set[e->lc.fin % (unsigned)e->lc.nsets];
+            const hipError_t st = hipEventQuery(q.ev_done);
+            if (st == hipErrorNotReady) { (void)hipGetLastError(); return FFV2AMD_ERR_AGAIN; }
+            HIPCHK(st);
+        }
+        const int rc = qpring_collect(e);
+        if (rc < 0) return rc;
+        if (r.count == r.cap) (void)qpring_submit(e);            // a full batch was waiting for this call's place
+    }
+    const int i = r.done_at;
+    if (tag) *tag = r.done_tags[(size_t)i];
+    const int32_t st = r.status[(size_t)i];
+    if (st < 0) { r.done_at++; return st; }                      // the frame has left the ring all the same
+    const size_t n = r.sizes[(size_t)i];
+    if (n > out_cap) return FFV2AMD_ERR_NOSPACE;
+    memcpy(out, r.h_buf + r.offs[(size_t)i], n);
+    *out_size = n;
+    r.done_at++;
     return FFV2AMD_OK;
 }
 

@@ -20,7 +20,8 @@ typedef struct FFV2AMDEncCtx {      /* the role of FFV2EncCtx, ffv2enc.c:29-53 *
     uint8_t *scratch;
     size_t scratch_cap;
     int ring_open;
-    int mode;                       /* frames in flight came in through: 0 nothing yet, 1 the ring (qp 0), 2 the qp > 0 pipeline */
+    int mode;                       /* frames in flight came in through: 0 nothing yet, 1 the ring (qp 0), 2 the qp > 0 pipeline, 3 the qp > 0 ring */
+    int qpring_qp;                  /* the qp > 0 rings are open for this qp (0: closed) */
     uint64_t sent, received;        /* frame n lives on device n % ndev */
     int verbose;                    /* FFV2AMD_VERBOSE: the reference's per-frame size line */
 } FFV2AMDEncCtx;
@@ -191,14 +192,38 @@ int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *fra
     FFV2AMDEncCtx *s;
     ffv2amd_encoder *enc;
     const int qp = avctx ? avctx->global_quality : 0;
-    int ret;
-    if (!avctx || !avctx->priv_data || !frame || qp < 0)
+    int ret, mode;
+    if (!avctx || !avctx->priv_data || qp < 0)
         return FFV2AMD_ERR_INVAL;
     s = avctx->priv_data;
-    if (s->sent != s->received && s->mode != (qp > 0 ? 2 : 1))
+    if (!frame) {                               /* end of stream: batches that are not full yet go out */
+        if (s->mode == 3)
+            for (int d = 0; d < s->ndev; d++)
+                if ((ret = ffv2amd_qpring_flush(s->encs[d])) < 0)
+                    return ret;
+        return 0;
+    }
+    mode = qp > 0 ? (avctx->qp_frames_per_call > 0 ? 3 : 2) : 1;
+    if (s->sent != s->received && s->mode != mode)
         return FFV2AMD_ERR_INVAL;               /* global_quality changed with frames in flight */
     enc = s->encs[s->sent % (uint64_t)s->ndev];
-    if (qp > 0) {
+    if (mode == 3) {
+        if (s->qpring_qp != qp) {
+            if (s->sent != s->received)
+                return FFV2AMD_ERR_INVAL;
+            for (int d = 0; d < s->ndev; d++)
+                ffv2amd_qpring_close(s->encs[d]);
+            s->qpring_qp = 0;
+            for (int d = 0; d < s->ndev; d++)
+                if ((ret = ffv2amd_qpring_open(s->encs[d], qp, avctx->qp_frames_per_call, 0)) < 0) {
+                    while (d-- > 0)
+                        ffv2amd_qpring_close(s->encs[d]);
+                    return ret;
+                }
+            s->qpring_qp = qp;
+        }
+        ret = ffv2amd_qpring_send(enc, frame->data, frame->linesize, NULL, frame->pts, flags & (FFV2AMD_FRAME_PINNED | FFV2AMD_FRAME_YUV420));
+    } else if (mode == 2) {
         ret = flags & FFV2AMD_FRAME_YUV420
             ? ffv2amd_qp_send_frame_420(enc, frame->data, frame->linesize, qp, frame->pts)
             : ffv2amd_qp_send_frame(enc, frame->data, frame->linesize, qp, NULL, frame->pts);
@@ -218,7 +243,7 @@ int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *fra
     }
     if (ret < 0)
         return ret;
-    s->mode = qp > 0 ? 2 : 1;
+    s->mode = mode;
     s->sent++;
     return 0;
 }
@@ -236,7 +261,11 @@ int ffv2amd_codec_receive_packet(FFV2AMDCodecContext *avctx, FFV2AMDPacket *avpk
     if (s->received == s->sent)
         return FFV2AMD_ERR_AGAIN;
     enc = s->encs[s->received % (uint64_t)s->ndev];
-    if (s->mode == 2) {
+    if (s->mode == 3) {
+        if ((ret = grow_scratch(s, s->info.packet_cap_qp)) < 0)
+            return ret;
+        ret = ffv2amd_qpring_receive(enc, s->scratch, s->scratch_cap, &n, &pts, wait);
+    } else if (s->mode == 2) {
         if ((ret = grow_scratch(s, s->info.packet_cap_qp)) < 0)
             return ret;
         ret = ffv2amd_qp_receive_packet(enc, s->scratch, s->scratch_cap, &n, &pts);

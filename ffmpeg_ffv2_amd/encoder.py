@@ -471,6 +471,62 @@ class FFV2Encoder:
         _lib.check(r, "ring_receive")
         return tag.value, self._ring_out[: n.value].tobytes()
 
+    # ---- send_frame / receive_packet at qp > 0 on top of the lane coder (ffv2amd_qpring_*) ----
+    def qpring_open(self, qp, frames_per_call, packet_cap=0):
+        _lib.check(self._lib.ffv2amd_qpring_open(self._h, int(qp), int(frames_per_call), int(packet_cap)), "qpring_open")
+        cap = packet_cap or self.info.packet_cap_qp
+        self._qpring_out = np.empty(int(cap) + 16, np.uint8)
+
+    def qpring_send(self, frame, tag=0, W=None, pinned=False, yuv420=False):
+        """frame: (P,H,W) host array, or with yuv420=True the (Y, U, V) arrays of a yuv420p* frame.  False: EAGAIN
+        (receive packets first, then send the frame again)."""
+        i = self.info
+        planes = list(frame) if yuv420 else [frame[p] for p in range(i.planes)]
+        data = (C.c_void_p * 4)()
+        ls = (C.c_ssize_t * 4)()
+        for p, a in enumerate(planes):
+            assert a.dtype == self.dtype and a.strides[1] == self.dtype.itemsize, (a.dtype, a.strides)
+            data[p] = a.ctypes.data
+            ls[p] = a.strides[0]
+        wp = None
+        if W is not None:
+            W = np.ascontiguousarray(W, np.int32)
+            assert W.size == i.block_planes
+            wp = W.ctypes.data_as(C.c_void_p)
+        r = self._lib.ffv2amd_qpring_send(self._h, data, ls, wp, int(tag), (1 if pinned else 0) | (2 if yuv420 else 0))
+        if r == -11:
+            return False
+        _lib.check(r, "qpring_send")
+        return True
+
+    def qpring_flush(self):
+        r = self._lib.ffv2amd_qpring_flush(self._h)
+        if r == -11:
+            return False
+        _lib.check(r, "qpring_flush")
+        return True
+
+    def qpring_receive(self, wait=True):
+        """-> (tag, packet bytes), or None (EAGAIN).  A frame the reference would abort on raises FFV2Error(-1) and
+        leaves the ring (its tag is in the exception's `tag`)."""
+        n = C.c_size_t(0)
+        tag = C.c_int64(0)
+        r = self._lib.ffv2amd_qpring_receive(self._h, self._qpring_out.ctypes.data_as(C.c_void_p), self._qpring_out.size,
+                                             C.byref(n), C.byref(tag), 1 if wait else 0)
+        if r == -11:
+            return None
+        if r < 0:
+            e = _lib.FFV2Error(r, "qpring_receive")
+            e.tag = tag.value
+            raise e
+        return tag.value, self._qpring_out[: n.value].tobytes()
+
+    def qpring_pending(self):
+        return self._lib.ffv2amd_qpring_pending(self._h)
+
+    def qpring_close(self):
+        _lib.check(self._lib.ffv2amd_qpring_close(self._h), "qpring_close")
+
     def pinned_frames(self, count):
         """(count,P,H,W) sample array in page-locked host memory (row stride = the device row
         pitch), for ring_send(pinned=True).  Free with free_pinned()."""

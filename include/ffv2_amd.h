@@ -184,6 +184,38 @@ int  ffv2amd_qp_send_frame_420(ffv2amd_encoder *enc, const uint8_t *const data[3
 int  ffv2amd_qp_receive_packet(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag);
 int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
 
+/* == avcodec_send_frame / avcodec_receive_packet at qp > 0 AT THE DEVICE CODER'S RATE (reference encode.c:420,449
+ * around ffv2enc.c:453; round 3).  ffv2amd_qp_send_frame above codes one frame per call with the host-thread coder
+ * (tens of milliseconds per 1080p frame); this ring is the same boundary on top of the lane coder below: frames in
+ * host memory are collected `frames_per_call` at a time in device memory as they arrive (H2D on the ring's own
+ * stream, a 4:2:0 frame up-converted there), every full batch is one lane coder call (two in flight), and the
+ * packets come back in send order, byte-identical to ffv2amd_encode_batch_to_host at that qp.
+ *   qpring_open    : qp 1..64; HBM for three batches of frames plus the lane coder's scratch
+ *                    (ffv2amd_lanecoder_bytes_per_frame(enc, packet_cap, 2) per frame), page-locked host memory
+ *                    for one batch of packets; FFV2AMD_ERR_NOMEM if it does not fit.  Throughput grows with
+ *                    frames_per_call (hundreds to thousands), and so does the delay: a packet comes back once
+ *                    its whole batch is through.
+ *   qpring_send    : flags FFV2AMD_FRAME_PINNED (planes page-locked and untouched until the frame's packet has
+ *                    been received: the DMA engine reads them in place) and/or FFV2AMD_FRAME_YUV420 (data = Y, U, V
+ *                    of a yuv420p* frame); otherwise the rows are copied before the call returns.
+ *                    FFV2AMD_ERR_AGAIN: a batch is full, two calls are in flight and the packets of the one
+ *                    before them have not all been received -- receive, then send the frame again.
+ *   qpring_flush   : end of stream (avcodec_send_frame(NULL)): the partly filled batch goes out.  FFV2AMD_ERR_AGAIN
+ *                    as for send.
+ *   qpring_receive : next packet in send order with the tag given at send; FFV2AMD_ERR_AGAIN when none is ready
+ *                    (wait == 0) or nothing has been submitted (send more frames, or flush); with wait != 0 it
+ *                    blocks until the oldest batch in flight is through.  A frame the reference would abort on
+ *                    returns FFV2AMD_ERR_ABORT and leaves the ring.
+ * One thread drives a ring; while it is open the encoder's lane coder entry points are the ring's.  PARITY
+ * UNPINNED like all of qp > 0. */
+int  ffv2amd_qpring_open(ffv2amd_encoder *enc, int qp, int frames_per_call, size_t packet_cap);
+int  ffv2amd_qpring_send(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
+                         const int32_t *W, int64_t tag, unsigned flags);
+int  ffv2amd_qpring_flush(ffv2amd_encoder *enc);
+int  ffv2amd_qpring_receive(ffv2amd_encoder *enc, uint8_t *out, size_t out_cap, size_t *out_size, int64_t *tag, int wait);
+int  ffv2amd_qpring_pending(const ffv2amd_encoder *enc);
+int  ffv2amd_qpring_close(ffv2amd_encoder *enc);
+
 /* qp > 0 with MANY FRAMES IN FLIGHT (ffv2_lanecoder.hip).  The range coder
  * is one dependent chain per frame (ffv2enc.c:461,466), so the device codes many frames side by
  * side, one per lane of a wavefront, and does the rest (CDF rows as prefix counts, raw bits,

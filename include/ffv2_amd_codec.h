@@ -39,6 +39,12 @@ typedef struct FFV2AMDCodecContext {
      * in send order.  nb_devices <= 1: hip_device alone.  encode2 always runs on the first device. */
     int nb_devices;
     int hip_devices[FFV2AMD_MAX_DEVICES];
+    /* extension: global_quality > 0 through send_frame/receive_packet at the device coder's rate.  0 (default): one
+     * frame per call, coded by host threads (ffv2amd_qp_send_frame).  N > 0: frames are collected N at a time PER
+     * DEVICE and coded side by side on the device (ffv2amd_qpring_*, ffv2_lanecoder.hip); packets come back once their
+     * batch is through, so the caller drains with send_frame(NULL) at the end of the stream, as with any encoder
+     * that delays (the reference's encoder does not: ffv2enc.c:603-617 sets no AV_CODEC_CAP_DELAY). */
+    int qp_frames_per_call;
 } FFV2AMDCodecContext;
 
 typedef struct FFV2AMDFrame {

@@ -197,3 +197,60 @@ def test_yuv420_frames_at_qp_above_zero(oracle):
             want = None
         assert (pts, pk) == ((500 + n, want) if want is not None else (None, -1)), n
     assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_send_receive_at_qp_above_zero_through_the_device_coder(oracle, devices):
+    """qp_frames_per_call > 0: frames are collected per device and coded side by side on the device
+    (ffv2amd_qpring_*); send_frame(NULL) drains; order, pts and packets as with the one-frame pipeline; 4:2:0 frames
+    take the same road."""
+    lib = _lib()
+    W, H, qp = 200, 130, 16
+    frames = [synth.noise(170 + n, 3, H, W, 8) for n in range(11)]
+    flat = np.full((3, H, W), 200, np.uint8)
+    flat[0, 10, 10] = 0
+    frames[4] = flat                                           # the reference would av_assert0
+    ctx = make_ctx(W, H, 5, qp=qp, devices=devices, qp_frames_per_call=3)
+    assert lib.ffv2amd_codec_init(C.byref(ctx)) == 0
+    out, sent, drained = [], 0, False
+    while len(out) < len(frames):
+        while sent < len(frames):
+            r = lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(frames[sent], 900 + sent)), 0)
+            if r == -11:
+                break
+            assert r == 0, r
+            sent += 1
+        if sent == len(frames) and not drained:
+            r = lib.ffv2amd_codec_send_frame(C.byref(ctx), None, 0)                  # drain; EAGAIN: take packets first
+            assert r in (0, -11), r
+            drained = r == 0
+        pkt = Packet()
+        r = lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(pkt), 1)
+        if r == -11:
+            assert not drained
+            continue
+        if r < 0:
+            out.append((None, r))
+            continue
+        out.append((pkt.pts, bytes(pkt.data[: pkt.size])))
+        lib.ffv2amd_packet_unref(C.byref(pkt))
+    for n, (pts, pk) in enumerate(out):
+        if n == 4:
+            assert (pts, pk) == (None, -1)
+        else:
+            assert pts == 900 + n and pk == oracle.encode(frames[n], "yuv444p", qp=qp), n
+    # another qp with nothing in flight: the rings are reopened; 4:2:0 frames
+    ctx.global_quality = 4
+    cw, ch = (W + 1) // 2, (H + 1) // 2
+    f420 = [(synth.noise(30 + n, 1, H, W, 8)[0], synth.noise(40 + n, 1, ch, cw, 8)[0], synth.noise(50 + n, 1, ch, cw, 8)[0])
+            for n in range(4)]
+    for n, f in enumerate(f420):
+        assert lib.ffv2amd_codec_send_frame(C.byref(ctx), C.byref(frame_of(f, n)), FRAME_YUV420) == 0
+    assert lib.ffv2amd_codec_send_frame(C.byref(ctx), None, 0) == 0
+    for n, (y, u, v) in enumerate(f420):
+        pkt = Packet()
+        assert lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(pkt), 1) == 0 and pkt.pts == n
+        assert bytes(pkt.data[: pkt.size]) == oracle.encode(oracle.sws_420_to_444(y, u, v, 8), "yuv444p", qp=4), n
+        lib.ffv2amd_packet_unref(C.byref(pkt))
+    assert lib.ffv2amd_codec_receive_packet(C.byref(ctx), C.byref(Packet()), 1) == -11
+    assert lib.ffv2amd_codec_close(C.byref(ctx)) == 0

@@ -264,16 +264,19 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
     enc.lanecoder_close()
     i = enc.info
     W, H = i.width, i.height
-    per_call = max(64, min(F // 2, 2048) // 64 * 64)
-    total = 4 * per_call
+    # a call lasts at least one frame's range chain (0.6 s for 1080p noise at qp 16) whatever it holds: large batches
+    per_call = max(64, min(F // 2, 4096) // 64 * 64)
+    total = 6 * per_call
     nsrc = host_frames.shape[0]
     out = {"frames_per_call": per_call, "frames_sent": total, "what":
            "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
            "flight) -> ffv2amd_qpring_receive: packets in host memory in send order; pinned: page-locked frames read in "
-           "place; pageable: rows copied by the calling thread into page-locked bounce frames; yuv420: the literal 4:2:0 "
+           "place; pageable: rows copied by the calling thread into page-locked bounce frames; pageable_registered: ordinary "
+           "memory from a pool of buffers, page-locked by the ring on first sight (FFV2AMD_FRAME_REGISTER); yuv420: the literal 4:2:0 "
            "frames, up-converted on the device"}
     y420 = [yuv420_of(f) for f in host_frames] if i.planes == 3 else None
-    for name, pinned, is420 in [("pinned", True, False), ("pageable", False, False), ("yuv420_pinned", True, True)]:
+    for name, pinned, is420 in [("pinned", True, False), ("pageable", False, False), ("pageable_registered", False, False),
+                                ("yuv420_pinned", True, True)]:
         if is420 and y420 is None:
             continue
         if pinned and not is420:
@@ -292,7 +295,8 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
         got, sent, first, flushed = 0, 0, None, False
         t0 = time.perf_counter()
         while got < total:
-            while sent < total and enc.qpring_send(src[sent % nsrc], tag=sent, pinned=pinned, yuv420=is420):
+            while sent < total and enc.qpring_send(src[sent % nsrc], tag=sent, pinned=pinned, yuv420=is420,
+                                                   register=name.endswith("registered")):
                 sent += 1
             if sent == total and not flushed:
                 flushed = enc.qpring_flush()

@@ -2233,6 +2233,8 @@ int ffv2amd_qp_receive_packet(ffv2amd_encoder *e, uint8_t *out, size_t out_cap, 
 // this ring collects them `frames_per_call` at a time in device memory as they arrive (H2D on its own stream),
 // hands every full batch to the lane coder (two calls in flight) and gives the packets back in send order.
 // ---------------------------------------------------------------------------------------------
+static bool host_range_registered(ffv2amd_encoder *e, const uint8_t *src, size_t need);
+
 int ffv2amd_qpring_close(ffv2amd_encoder *e)
 {
     if (!e) return FFV2AMD_ERR_INVAL;
@@ -2255,6 +2257,10 @@ int ffv2amd_qpring_close(ffv2amd_encoder *e)
     }
     if (r.h_buf) (void)hipHostFree(r.h_buf);
     r.h_buf = nullptr; r.h_cap = 0;
+    if (e->ring.empty()) {                                        // FFV2AMD_FRAME_REGISTER: what this encoder page-locked (the frame ring is not using it)
+        for (auto &g : e->ring_reg) (void)hipHostUnregister((void *)g.base);
+        e->ring_reg.clear();
+    }
     if (r.ev_batch) (void)hipEventDestroy(r.ev_batch);
     if (r.h2d) (void)hipStreamDestroy(r.h2d);
     r.ev_batch = nullptr; r.h2d = nullptr;
@@ -2379,7 +2385,14 @@ int ffv2amd_qpring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const 
         pl[p].dst = chroma ? d_c + (size_t)(p - 1) * c_pitch * (size_t)ch : d_frame + (size_t)(is420 ? 0 : p) * in.plane_stride;
     }
     hipStream_t sh = r.h2d;
-    if (flags & FFV2AMD_FRAME_PINNED) {
+    bool in_place = (flags & FFV2AMD_FRAME_PINNED) != 0;
+    if (!in_place && (flags & FFV2AMD_FRAME_REGISTER)) {         // pageable memory from a pool: page-locked on first sight
+        in_place = true;
+        for (int p = 0; p < npl; p++)
+            in_place = in_place && pl[p].ls > 0 &&
+                       host_range_registered(e, pl[p].src, (size_t)pl[p].ls * (size_t)(pl[p].rows - 1) + pl[p].row_bytes);
+    }
+    if (in_place) {
         for (int p = 0; p < npl; p++) {
             if (pl[p].ls == (ptrdiff_t)pl[p].pitch)
                 HIPCHK(hipMemcpyAsync(pl[p].dst, pl[p].src, pl[p].pitch * (size_t)(pl[p].rows - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh));
@@ -2655,6 +2668,21 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
 
 int ffv2amd_ring_pending(const ffv2amd_encoder *e) { return e ? e->ring_count : 0; }
 
+// FFV2AMD_FRAME_REGISTER: is [src, src + need) page-locked by this encoder -- on first sight of a buffer it becomes so
+// (hipHostRegister: milliseconds, once per buffer of the caller's pool), afterwards the cache answers.
+static bool host_range_registered(ffv2amd_encoder *e, const uint8_t *src, size_t need)
+{
+    for (const auto &g : e->ring_reg)
+        if (g.base <= src && src + need <= g.base + g.bytes) return true;
+    if (e->ring_reg.size() >= 256) return false;
+    if (hipHostRegister((void *)src, need, hipHostRegisterDefault) == hipSuccess) {
+        try { e->ring_reg.push_back({ src, need }); return true; }
+        catch (...) { (void)hipHostUnregister((void *)src); return false; }
+    }
+    (void)hipGetLastError();                  // not registrable (already part of another registration, ...)
+    return false;
+}
+
 // One plane of a frame on its way into a ring slot: `rows` rows of `row_bytes` bytes from the caller's
 // (src, linesize) to device memory (d_dst, rows pitch bytes apart); `stage` is the slot's page-locked
 // copy of it, used when the caller's memory is pageable.
@@ -2682,16 +2710,7 @@ static int ring_submit(ffv2amd_encoder *e, ffv2amd_encoder::RingSlot &r, const R
         if (flags & FFV2AMD_FRAME_PINNED) { direct[i] = true; continue; }
         if (!(flags & FFV2AMD_FRAME_REGISTER) || q.linesize <= 0) continue;
         const size_t need = (size_t)q.linesize * (size_t)(q.rows - 1) + q.row_bytes;
-        for (const auto &g : e->ring_reg)
-            if (g.base <= q.src && q.src + need <= g.base + g.bytes) { direct[i] = true; break; }
-        if (!direct[i] && e->ring_reg.size() < 256) {
-            if (hipHostRegister((void *)q.src, need, hipHostRegisterDefault) == hipSuccess) {
-                try { e->ring_reg.push_back({ q.src, need }); direct[i] = true; }
-                catch (...) { (void)hipHostUnregister((void *)q.src); }
-            } else {
-                (void)hipGetLastError();          // not registrable (already part of another registration, ...): gather it
-            }
-        }
+        direct[i] = host_range_registered(e, q.src, need);       // false: gather it
     }
     int ngather = 0;
     for (int i = 0; i < npl; i++) {

@@ -222,7 +222,8 @@ int ffv2amd_codec_send_frame(FFV2AMDCodecContext *avctx, const FFV2AMDFrame *fra
                 }
             s->qpring_qp = qp;
         }
-        ret = ffv2amd_qpring_send(enc, frame->data, frame->linesize, NULL, frame->pts, flags & (FFV2AMD_FRAME_PINNED | FFV2AMD_FRAME_YUV420));
+        ret = ffv2amd_qpring_send(enc, frame->data, frame->linesize, NULL, frame->pts,
+                                  flags & (FFV2AMD_FRAME_PINNED | FFV2AMD_FRAME_YUV420 | FFV2AMD_FRAME_REGISTER));
     } else if (mode == 2) {
         ret = flags & FFV2AMD_FRAME_YUV420
             ? ffv2amd_qp_send_frame_420(enc, frame->data, frame->linesize, qp, frame->pts)

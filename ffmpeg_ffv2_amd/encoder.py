@@ -477,7 +477,7 @@ class FFV2Encoder:
         cap = packet_cap or self.info.packet_cap_qp
         self._qpring_out = np.empty(int(cap) + 16, np.uint8)
 
-    def qpring_send(self, frame, tag=0, W=None, pinned=False, yuv420=False):
+    def qpring_send(self, frame, tag=0, W=None, pinned=False, yuv420=False, register=False):
         """frame: (P,H,W) host array, or with yuv420=True the (Y, U, V) arrays of a yuv420p* frame.  False: EAGAIN
         (receive packets first, then send the frame again)."""
         i = self.info
@@ -493,7 +493,8 @@ class FFV2Encoder:
             W = np.ascontiguousarray(W, np.int32)
             assert W.size == i.block_planes
             wp = W.ctypes.data_as(C.c_void_p)
-        r = self._lib.ffv2amd_qpring_send(self._h, data, ls, wp, int(tag), (1 if pinned else 0) | (2 if yuv420 else 0))
+        r = self._lib.ffv2amd_qpring_send(self._h, data, ls, wp, int(tag),
+                                          (1 if pinned else 0) | (2 if yuv420 else 0) | (4 if register else 0))
         if r == -11:
             return False
         _lib.check(r, "qpring_send")

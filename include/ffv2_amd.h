@@ -196,8 +196,10 @@ int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
  *                    frames_per_call (hundreds to thousands), and so does the delay: a packet comes back once
  *                    its whole batch is through.
  *   qpring_send    : flags FFV2AMD_FRAME_PINNED (planes page-locked and untouched until the frame's packet has
- *                    been received: the DMA engine reads them in place) and/or FFV2AMD_FRAME_YUV420 (data = Y, U, V
- *                    of a yuv420p* frame); otherwise the rows are copied before the call returns.
+ *                    been received: the DMA engine reads them in place), FFV2AMD_FRAME_REGISTER (the same promise for
+ *                    ordinary memory from a pool of long-lived buffers, page-locked here on first sight) and/or
+ *                    FFV2AMD_FRAME_YUV420 (data = Y, U, V of a yuv420p* frame); otherwise the rows are copied before
+ *                    the call returns.
  *                    FFV2AMD_ERR_AGAIN: a batch is full, two calls are in flight and the packets of the one
  *                    before them have not all been received -- receive, then send the frame again.
  *   qpring_flush   : end of stream (avcodec_send_frame(NULL)): the partly filled batch goes out.  FFV2AMD_ERR_AGAIN

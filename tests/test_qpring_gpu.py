@@ -137,3 +137,26 @@ def test_qpring_arguments_and_reopen(oracle):
     enc.qpring_close()
     assert enc.encode_batch_to_host(enc.upload(f[None]), qp=4) == [_want(oracle, f, "gray", 4)]
     enc.close()
+
+
+def test_qpring_registers_pooled_pageable_frames(oracle):
+    """FFV2AMD_FRAME_REGISTER: a pool of two ordinary buffers, refilled after their packets have come back; the ring
+    page-locks each on first sight and reads it in place from then on."""
+    W_, H_, fmt, qp = 150, 100, "yuv444p", 16
+    enc = _enc(W_, H_, fmt)
+    pool = [np.empty((3, H_, W_), np.uint8) for _ in range(2)]
+    frames = [synth.noise(300 + i, 3, H_, W_, 8) for i in range(6)]
+    enc.qpring_open(qp, 2)
+    got = []
+    for base in range(0, 6, 2):
+        for k in range(2):
+            pool[k][:] = frames[base + k]
+            assert enc.qpring_send(pool[k], tag=base + k, register=True)
+        # the batch of two is on its way; its packets back before the buffers are written again
+        while len(got) < base + 2:
+            _drain(enc, got, wait=True)
+    assert [t for t, _ in got] == list(range(6))
+    for i, (_, pk) in enumerate(got):
+        assert pk == _want(oracle, frames[i], fmt, qp), i
+    enc.qpring_close()
+    enc.close()

@@ -216,13 +216,17 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
             divs = div_per_bp * enc.info.block_planes * nq
             rate = divs / (ms.value * 1e-3)
             peak = 256 * 4 * 16 * 2.4e9 / 11            # CUs x SIMDs x lanes x clock / instructions of the division sequence
-            res["roofline"] = {"bound": "valu (IEEE f32 division, 11 instructions)", "kernel": "ffv2_pvq_kernel",
+            general = args.qp > 64 or os.environ.get("FFV2AMD_PVQ_GENERAL", "0") not in ("", "0")
+            res["roofline"] = {"bound": "valu (IEEE f32 division, 11 instructions)",
+                               "kernel": "ffv2_pvq_kernel" if general else "ffv2_pvq_lists_kernel",
                                "achieved": round(rate / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T divisions/s",
                                "frac": round(rate / peak, 3), "traffic": None,
                                "kernel_ms_avg": round(ms.value, 4), "frames_per_launch": nq,
                                "divisions_per_block_plane": div_per_bp,
-                               "what": "ffv2_pvq_kernel alone, %d frames per launch, 10 launches; divisions = elements x pulses "
-                                       "(upper bound: every pulse searched); peak = f32 VALU lanes x 2.4 GHz / 11" % nq}
+                               "what": "the Q-stage kernel alone, %d frames per launch, 10 launches; divisions = ALGORITHMIC: elements x "
+                                       "pulses as the reference's search performs them (celt_pvq_search.asm:85-191; upper bound: every "
+                                       "pulse searched) -- the list search reaches the same pulses with far fewer; peak = f32 VALU "
+                                       "lanes x 2.4 GHz / 11" % nq}
         except Exception as ex:
             res["roofline"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_host_boundary:

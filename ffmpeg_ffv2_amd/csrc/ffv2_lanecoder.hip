@@ -159,19 +159,60 @@ __global__ __launch_bounds__(64) void lc_scan_kernel(const FFV2LaneCoderArgs a)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs a, const int16_t *y)
 {
+    // Everything the block-plane needs from memory is asked for at the top -- its pulses go to LDS in 16-byte pieces, the
+    // thirteen row positions / lengths / counts and the sixteen code words into one lane each -- and waited for once:
+    // from there on the kernel only computes and stores (loads and stores share a wait counter on this chip: a load in
+    // the loop would wait for every store before it).
     __shared__ uint32_t sink[64];
+    __shared__ __attribute__((aligned(16))) int16_t ys[FFV2_Y_STRIDE + 8];
     const int fl = blockIdx.y, f = a.f0 + fl, bp = blockIdx.x, lane = threadIdx.x;
     const int nb = a.nblk;
     const int16_t *yy = y + ((size_t)fl * nb + bp) * FFV2_Y_STRIDE;
     const FFV2SymRec *r = a.cnt + (size_t)f * nb + bp;
     const uint32_t *cr = a.codes + ((size_t)f * nb + bp) * FFV2_CODES_PER_BP;
     const uint32_t *rowbase = a.rowbase + (size_t)f * 13 * (nb + 1);
-    const uint32_t gb = a.gbase[(size_t)f * (nb + 1) + bp];
-    const uint32_t bit0 = a.rawbase[(size_t)f * (nb + 1) + bp];
     uint8_t *rows = a.rows + (size_t)f * a.row_stride;
     uint32_t *raw = a.raw + (size_t)f * a.raw_words;
 
+    static_assert(FFV2_Y_STRIDE % 8 == 0, "whole 16-byte pieces");
+    constexpr int NV = FFV2_Y_STRIDE / 8;                           // 513
+    const uint4 *yv = reinterpret_cast<const uint4 *>(yy);          // 16-byte aligned: FFV2_Y_STRIDE * 2 is a multiple of 16
+    uint4 *sv = reinterpret_cast<uint4 *>(ys);
+    uint4 stage[(NV + 63) / 64];
+#pragma unroll
+    for (int v = 0; v < (NV + 63) / 64; v++) {
+        const int i = lane + 64 * v;
+        stage[v] = yv[i < NV ? i : NV - 1];
+    }
+    const int bl = lane < FFV2_NUM_BANDS ? lane : FFV2_NUM_BANDS - 1;
+    const uint32_t my_rb = rowbase[(size_t)bl * (nb + 1) + bp];     // lane b: where band b of this block-plane starts in row b
+    const uint32_t my_len = rowbase[(size_t)bl * (nb + 1) + nb];    // ... the length of row b
+    const uint32_t my_cnt = r->count[bl];                           // ... symbols the coder reads of the band
+    const uint32_t my_cr = cr[lane < FFV2_CODES_PER_BP ? lane : 0]; // lane i: code word i (0: the DC coefficient, 1 + b: band b's gain)
+    const uint32_t gb = a.gbase[(size_t)f * (nb + 1) + bp];
+    const uint32_t bit0 = a.rawbase[(size_t)f * (nb + 1) + bp];
+#pragma unroll
+    for (int v = 0; v < (NV + 63) / 64; v++) {
+        const int i = lane + 64 * v;
+        if (i < NV) sv[i] = stage[v];
+    }
     sink[lane] = 0;
+    // the fourteen Exp-Golomb codes side by side (ffv2enc.c:105-123), one lane each
+    int my_glen = 0;
+    unsigned long long my_gcode = 0;
+    {
+        const int c0 = (int)my_cr;
+        const uint32_t val = lane == 0 ? (c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0) : my_cr;
+        if (lane <= FFV2_NUM_BANDS) my_gcode = golomb_code(val, &my_glen);
+    }
+    // rows lie back to back: row b starts at the sum of the lengths before it
+    uint32_t my_rowoff = my_len;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)my_rowoff, o, 64);
+        if (lane >= o) my_rowoff += t;
+    }
+    my_rowoff -= my_len;                                            // exclusive
     __syncthreads();
     // raw bits of this block-plane, assembled at their bit offset modulo 32 (ffv2enc.c:148-150,174,183-184)
     uint32_t pos = bit0 & 31u;
@@ -185,67 +226,43 @@ __global__ __launch_bounds__(64) void lc_scatter_kernel(const FFV2LaneCoderArgs 
         }
         pos += (uint32_t)len;
     };
+    auto code_of = [&](int i, int *len) {                          // lane i's code, for every lane
+        *len = __shfl(my_glen, i, 64);
+        return ((unsigned long long)(uint32_t)__shfl((int)(my_gcode >> 32), i, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)my_gcode, i, 64);
+    };
     {
-        const int c0 = (int)cr[0];
+        const int c0 = (int)(uint32_t)__shfl((int)my_cr, 0, 64);
         int len;
-        const unsigned long long code = golomb_code(c0 < 0 ? (uint32_t)(-(long long)c0) : (uint32_t)c0, &len);
+        const unsigned long long code = code_of(0, &len);
         put(code, len);
         if (c0) put(c0 < 0 ? 1u : 0u, 1);
     }
-    uint32_t rowoff = 0, before = 0;
+    uint32_t before = 0;
 #pragma unroll 1
     for (int b = 0; b < FFV2_NUM_BANDS; b++) {
         const int lo = 1 + LC_BS[b];
-        const uint32_t cntb = r->count[b];
-        const uint32_t rb = rowbase[(size_t)b * (nb + 1) + bp];
+        const uint32_t cntb = (uint32_t)__shfl((int)my_cnt, b, 64);
+        const uint32_t rb = (uint32_t)__shfl((int)my_rb, b, 64);
+        const uint32_t rowoff = (uint32_t)__shfl((int)my_rowoff, b, 64);
         if (lane == 0) a.delta[((size_t)f * 13 + b) * nb + bp] = gb + before - rb;
         int len;
-#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 4)
-        len = 3; const unsigned long long code = 5;
-#else
-        const unsigned long long code = golomb_code(cr[1 + b], &len);
-#endif
+        const unsigned long long code = code_of(1 + b, &len);
         put(code, len);
         uint8_t *dst = rows + rowoff + rb;
-        // eight rows of 64 pulses at a time: their loads are in flight together (the kernel is the latency of its
-        // loads: one row per trip was 64 trips per block-plane on noise)
-        for (uint32_t j0 = 0; j0 < cntb; j0 += 512) {
-            int qv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
-#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 2)
-                qv[u] = (int)(j & 1u);
-#else
-                qv[u] = j < cntb ? yy[lo + j] : 0;
-#endif
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t j = j0 + 64u * (uint32_t)u + (uint32_t)lane;
-                if (j0 + 64u * (uint32_t)u >= cntb) break;
-                const int q = qv[u];
-#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 1)
-                if (j == 0xFFFFFFFFu) dst[j] = (uint8_t)(q < 0 ? -q : q);
-#else
-                if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
-#endif
-                const unsigned long long nzm = __ballot(q != 0);
-                if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
-                pos += (uint32_t)__popcll(nzm);
-            }
+        for (uint32_t j0 = 0; j0 < cntb; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const int q = j < cntb ? ys[lo + j] : 0;
+            if (j < cntb) dst[j] = (uint8_t)(q < 0 ? -q : q);
+            const unsigned long long nzm = __ballot(q != 0);
+            if (q < 0) { const uint32_t p = pos + lane_prefix(nzm); atomicOr(&sink[p >> 5], 1u << (p & 31u)); }
+            pos += (uint32_t)__popcll(nzm);
         }
-        rowoff += rowbase[(size_t)b * (nb + 1) + nb];
         before += cntb;
     }
     __syncthreads();
     {
         const uint32_t nwords = (pos + 31u) >> 5, w0 = bit0 >> 5;
-#if defined(LC_SCAT_EXP) && (LC_SCAT_EXP & 8)
-        if ((uint32_t)lane < nwords && sink[lane] == 0x12345u && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
-#else
         if ((uint32_t)lane < nwords && sink[lane] && w0 + lane < a.raw_words) atomicOr(&raw[w0 + lane], sink[lane]);
-#endif
     }
     if (lane == 0 && bp == 0) atomicOr(&raw[0], a.header_bits);
 }

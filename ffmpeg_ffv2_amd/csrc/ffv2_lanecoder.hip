@@ -135,21 +135,31 @@ __global__ __launch_bounds__(64) void lc_scan_kernel(const FFV2LaneCoderArgs a)
     uint32_t *out = q < 13 ? a.rowbase + ((size_t)f * 13 + q) * (nb + 1)
                   : q == 13 ? a.gbase + (size_t)f * (nb + 1) : a.rawbase + (size_t)f * (nb + 1);
     uint32_t run = q == 13 ? 1u : q == 14 ? a.header_nbits : 0u;
-    for (int b0 = 0; b0 < nb; b0 += 64) {
-        const int bp = b0 + lane;
-        uint32_t v = 0, lead = 0;
-        if (bp < nb) {
-            v = q < 13 ? cnt[bp].count[q] : q == 13 ? cnt[bp].offset : bits[bp];
-            if (q >= 13 && bp % a.planes == 0) lead = q == 13 ? 1u : 4u;
-        }
-        uint32_t incl = v + lead;
+    // eight rows of 64 block-planes at a time: their loads are in flight together (one row per trip, the kernel was the
+    // latency of 24 loads in a row for a 1080p frame)
+    for (int b0 = 0; b0 < nb; b0 += 512) {
+        uint32_t vv[8], ll[8];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-            if (lane >= o) incl += t;
+        for (int u = 0; u < 8; u++) {
+            const int bp = b0 + 64 * u + lane, bc = bp < nb ? bp : nb - 1;   // loaded unconditionally, masked afterwards
+            const uint32_t got = q < 13 ? cnt[bc].count[q] : q == 13 ? cnt[bc].offset : bits[bc];
+            vv[u] = bp < nb ? got : 0u;
+            ll[u] = bp < nb && q >= 13 && bp % a.planes == 0 ? (q == 13 ? 1u : 4u) : 0u;
         }
-        if (bp < nb) out[bp] = run + incl - v;                     // exclusive, behind this block-plane's lead
-        run += (uint32_t)__shfl((int)incl, 63, 64);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int bp = b0 + 64 * u + lane;
+            if (b0 + 64 * u >= nb) break;
+            const uint32_t v = vv[u];
+            uint32_t incl = v + ll[u];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (bp < nb) out[bp] = run + incl - v;                     // exclusive, behind this block-plane's lead
+            run += (uint32_t)__shfl((int)incl, 63, 64);
+        }
     }
     if (lane == 0) out[nb] = run;
 }

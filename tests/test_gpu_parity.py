@@ -407,6 +407,20 @@ def test_raw_frame_cli_reproduces_reference_md5(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert dst.read_bytes() == oracle.encode(oracle.sws_420_to_444(y, u, v, 8), "yuv444p")
+    # --async N: send_frame / receive_packet instead of encode2, same bytes -- the ring at qp 0, batches of N frames on
+    # the device coder at qp 16 (the last batch partly filled: drained with send_frame(NULL)); 4:2:0 frames too
+    cli = os.path.join(root, "examples", "ffv2enc_cli")
+    for qp in ("0", "16"):
+        for n in ("2", "4"):
+            ref, got = tmp_path / ("sync%s.ffv2" % qp), tmp_path / ("async%s_%s.ffv2" % (qp, n))
+            assert subprocess.run([cli, "320", "240", "yuv444p", str(src), str(ref), qp], capture_output=True).returncode == 0
+            r = subprocess.run([cli, "320", "240", "yuv444p", str(src), str(got), qp, "0", "--async", n], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert got.read_bytes() == ref.read_bytes() and len(ref.read_bytes()) > 0, (qp, n)
+    got = tmp_path / "async420.ffv2"
+    r = subprocess.run([cli, "320", "240", "yuv420p", str(src420), str(got), "16", "0", "--async", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert got.read_bytes() == oracle.encode(oracle.sws_420_to_444(y, u, v, 8), "yuv444p", qp=16)
 
 
 def test_avcodec_shaped_shim(oracle):

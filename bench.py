@@ -234,6 +234,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
             # (ffv2amd_qpring_*: what send_frame / receive_packet reach with qp_frames_per_call set)
             try:
                 first = buf[int(offs[0]): int(offs[0]) + int(sizes[0])].tobytes()
+                d_frames = None                  # the resident frames' HBM is the ring's now
+                torch.cuda.empty_cache()
                 res["host_boundary"] = qp_host_boundary(args, enc, host_frames, F, first)
             except Exception as ex:
                 res["host_boundary"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -295,7 +297,17 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
             src = pool
         else:
             src = [host_frames[n] for n in range(nsrc)]
-        enc.qpring_open(args.qp, per_call, args.packet_cap)
+        from ffmpeg_ffv2_amd._lib import FFV2Error
+        while True:                              # smaller batches if the device cannot hold three of them and the coder's scratch
+            try:
+                enc.qpring_open(args.qp, per_call, args.packet_cap)
+                break
+            except FFV2Error as ex:
+                if ex.code != -12 or per_call <= 64:
+                    raise
+                per_call = max(64, per_call // 2 // 64 * 64)
+                total = 6 * per_call
+                out["frames_per_call"], out["frames_sent"] = per_call, total
         got, sent, first, flushed = 0, 0, None, False
         t0 = time.perf_counter()
         while got < total:

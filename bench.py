@@ -272,7 +272,7 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
     W, H = i.width, i.height
     # a call lasts at least one frame's range chain (0.6 s for 1080p noise at qp 16) whatever it holds: large batches
     per_call = max(64, min(F // 2, 4096) // 64 * 64)
-    total = 6 * per_call
+    total = 8 * per_call                         # filling and draining the pipeline included
     nsrc = host_frames.shape[0]
     out = {"frames_per_call": per_call, "frames_sent": total, "what":
            "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
@@ -306,7 +306,7 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
                 if ex.code != -12 or per_call <= 64:
                     raise
                 per_call = max(64, per_call // 2 // 64 * 64)
-                total = 6 * per_call
+                total = 8 * per_call                         # filling and draining the pipeline included
                 out["frames_per_call"], out["frames_sent"] = per_call, total
         got, sent, first, flushed = 0, 0, None, False
         t0 = time.perf_counter()

@@ -1573,8 +1573,16 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     FFV2LaneCoderArgs &a = lc.a;
     lc.nsets = nsets;
     a.nblk = (int)nb; a.planes = in.planes;
+    // Frames (lanes) per chain workgroup.  With thousands of frames in flight a call is bound by its throughput kernels
+    // and the chain hides behind them: 64 lanes, few workgroups.  With fewer frames the call lasts as long as one frame's
+    // chain, and a chain step is a little shorter with few active lanes (17 % at 4 lanes: 20.2 -> 16.8 ms per window of
+    // 1 024 1080p frames) while most SIMDs have nothing to do: about 512 workgroups then.  FFV2AMD_LC_WIDTH overrides.
+    static const int wenv = getenv("FFV2AMD_LC_WIDTH") ? atoi(getenv("FFV2AMD_LC_WIDTH")) : 0;
+    int wmax = 64;
+    if (wenv >= 1) wmax = wenv;
+    else if (frames <= 4096) { wmax = 4; while (wmax < 64 && (frames + wmax - 1) / wmax > 512) wmax <<= 1; }
     int width = 1;
-    while (width < frames && width < 64) width <<= 1;
+    while (width < frames && width < 64 && width < wmax) width <<= 1;
     a.width = width;
     const size_t groups = (F + width - 1) / width;
     const size_t maxsym = ((1 + nsb + nb * 4097) + 15) / 16 * 16;

@@ -1573,14 +1573,15 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     FFV2LaneCoderArgs &a = lc.a;
     lc.nsets = nsets;
     a.nblk = (int)nb; a.planes = in.planes;
-    // Frames (lanes) per chain workgroup.  With thousands of frames in flight a call is bound by its throughput kernels
-    // and the chain hides behind them: 64 lanes, few workgroups.  With fewer frames the call lasts as long as one frame's
-    // chain, and a chain step is a little shorter with few active lanes (17 % at 4 lanes: 20.2 -> 16.8 ms per window of
-    // 1 024 1080p frames) while most SIMDs have nothing to do: about 512 workgroups then.  FFV2AMD_LC_WIDTH overrides.
+    // Frames (lanes) per chain workgroup: as few as give about 256 workgroups (at most 333), 4 to 64.  A chain step is
+    // shorter with few active lanes (20.2 -> 16.8 ms per window of 1 024 1080p frames from 64 lanes to 4), the chip has
+    // SIMDs to spare for a few hundred two-wavefront workgroups, and more than that get in the way of the next call's
+    // front.  Measured at 1080p / qp 16 against 64 lanes: 1 024 frames +17 %, 2 048 +38 %, 3 328 +25 %, 4 096 +22 %,
+    // 6 656 +7 to +12 %.  FFV2AMD_LC_WIDTH overrides.
     static const int wenv = getenv("FFV2AMD_LC_WIDTH") ? atoi(getenv("FFV2AMD_LC_WIDTH")) : 0;
-    int wmax = 64;
+    int wmax = 4;
     if (wenv >= 1) wmax = wenv;
-    else if (frames <= 4096) { wmax = 4; while (wmax < 64 && (frames + wmax - 1) / wmax > 512) wmax <<= 1; }
+    else while (wmax < 64 && (frames + wmax - 1) / wmax > 333) wmax <<= 1;
     int width = 1;
     while (width < frames && width < 64 && width < wmax) width <<= 1;
     a.width = width;

@@ -277,7 +277,7 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
     out = {"frames_per_call": per_call, "frames_sent": total, "what":
            "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
            "flight) -> ffv2amd_qpring_receive: packets in host memory in send order; pinned: page-locked frames read in "
-           "place; pageable: rows copied by the calling thread into page-locked bounce frames; pageable_registered: ordinary "
+           "place; pageable: rows copied by the ring's helper threads into page-locked bounce frames; pageable_registered: ordinary "
            "memory from a pool of buffers, page-locked by the ring on first sight (FFV2AMD_FRAME_REGISTER); yuv420: the literal 4:2:0 "
            "frames, up-converted on the device"}
     y420 = [yuv420_of(f) for f in host_frames] if i.planes == 3 else None

@@ -739,11 +739,12 @@ struct ffv2amd_encoder {
         hipStream_t h2d = nullptr;
         hipEvent_t ev_batch = nullptr;
         // page-locked bounce frames for pageable callers
-        static constexpr int NBOUNCE = 4;
-        uint8_t *bounce[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
-        int32_t *bounce_w[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
-        hipEvent_t ev_bounce[NBOUNCE] = { nullptr, nullptr, nullptr, nullptr };
+        static constexpr int NBOUNCE = 64;       // at most; nbounce of them in use: about 256 MB (a copy queued behind the
+        uint8_t *bounce[NBOUNCE] = {};           // coder's kernels takes a millisecond to start: with four frames of
+        hipEvent_t ev_bounce[NBOUNCE] = {};      // bounce memory the sender waited for every one of them)
+        int nbounce = 4;
         unsigned nb_seq = 0;
+        GatherPool *pool = nullptr;              // helper threads for the row copies of pageable frames
         // the batch finished last, waiting to be received
         uint8_t *h_buf = nullptr;
         size_t h_cap = 0;
@@ -2260,12 +2261,12 @@ int ffv2amd_qpring_close(ffv2amd_encoder *e)
     }
     for (int i = 0; i < ffv2amd_encoder::QpRing::NBOUNCE; i++) {
         if (r.bounce[i]) (void)hipHostFree(r.bounce[i]);
-        if (r.bounce_w[i]) (void)hipHostFree(r.bounce_w[i]);
         if (r.ev_bounce[i]) (void)hipEventDestroy(r.ev_bounce[i]);
-        r.bounce[i] = nullptr; r.bounce_w[i] = nullptr; r.ev_bounce[i] = nullptr;
+        r.bounce[i] = nullptr; r.ev_bounce[i] = nullptr;
     }
     if (r.h_buf) (void)hipHostFree(r.h_buf);
     r.h_buf = nullptr; r.h_cap = 0;
+    if (r.pool) { r.pool->shutdown(); delete r.pool; r.pool = nullptr; }
     if (e->ring.empty()) {                                        // FFV2AMD_FRAME_REGISTER: what this encoder page-locked (the frame ring is not using it)
         for (auto &g : e->ring_reg) (void)hipHostUnregister((void *)g.base);
         e->ring_reg.clear();
@@ -2309,6 +2310,21 @@ int ffv2amd_qpring_open(ffv2amd_encoder *e, int qp, int frames_per_call, size_t 
     } catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
     r.fill = 0; r.count = 0; r.nflight = 0; r.done_n = r.done_at = 0;
     r.open = true;
+    {
+        static const size_t mb = getenv("FFV2AMD_QPRING_BOUNCE_MB") ? (size_t)atol(getenv("FFV2AMD_QPRING_BOUNCE_MB")) : 256;
+        const size_t n = (mb << 20) / in.frame_stride;
+        r.nbounce = n < 4 ? 4 : n > (size_t)ffv2amd_encoder::QpRing::NBOUNCE ? ffv2amd_encoder::QpRing::NBOUNCE : (int)n;
+        if (r.nbounce > frames_per_call + 1) r.nbounce = frames_per_call + 1 < 4 ? 4 : frames_per_call + 1;
+    }
+    if (in.frame_stride >= ((size_t)2 << 20)) {                  // helpers for the row copies of pageable frames
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int want = getenv("FFV2AMD_GATHER_THREADS") ? atoi(getenv("FFV2AMD_GATHER_THREADS")) : 6;   // caller included
+        const int helpers = (int)hw >= want ? want - 1 : (hw > 1 ? (int)hw - 1 : 0);
+        if (helpers > 0) {
+            r.pool = new (std::nothrow) GatherPool;
+            if (r.pool) r.pool->start(helpers, e->device);
+        }
+    }
     return FFV2AMD_OK;
 }
 
@@ -2411,20 +2427,36 @@ int ffv2amd_qpring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const 
     } else {
         // pageable memory: through one of a few page-locked frames (complete when the call returns as far as the caller
         // is concerned: its rows are copied here)
-        const int k = (int)(r.nb_seq++ % (unsigned)ffv2amd_encoder::QpRing::NBOUNCE);
+        const int k = (int)(r.nb_seq++ % (unsigned)r.nbounce);
         if (!r.bounce[k]) {
             HIPCHK(hipHostMalloc(&r.bounce[k], in.frame_stride, hipHostMallocDefault));
             HIPCHK(hipEventCreateWithFlags(&r.ev_bounce[k], hipEventDisableTiming));
         } else {
             HIPCHK(hipEventSynchronize(r.ev_bounce[k]));
         }
-        uint8_t *at = r.bounce[k];
-        for (int p = 0; p < npl; p++) {
-            for (int y = 0; y < pl[p].rows; y++)
-                memcpy(at + (size_t)y * pl[p].pitch, pl[p].src + (ptrdiff_t)y * pl[p].ls, pl[p].row_bytes);
-            HIPCHK(hipMemcpyAsync(pl[p].dst, at, pl[p].pitch * (size_t)(pl[p].rows - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh));
-            at += pl[p].pitch * (size_t)pl[p].rows;
+        // rows are copied in slices, by the ring's helper threads where the picture is large enough to pay for the
+        // hand-over (FFV2AMD_GATHER_THREADS, caller included); every slice's DMA is queued as soon as it is copied
+        uint8_t *at[4];
+        at[0] = r.bounce[k];
+        for (int p = 1; p < npl; p++) at[p] = at[p - 1] + pl[p - 1].pitch * (size_t)pl[p - 1].rows;
+        const int per = r.pool ? 4 : 1, nsl = npl * per;
+        hipError_t up[16];
+        for (int i = 0; i < nsl; i++) up[i] = hipSuccess;
+        const std::function<void(int)> slice = [&](int i) {
+            const int p = i / per, q = i % per;
+            const int y0 = (int)((long long)pl[p].rows * q / per), y1 = (int)((long long)pl[p].rows * (q + 1) / per);
+            if (y1 <= y0) return;
+            for (int y = y0; y < y1; y++)
+                memcpy(at[p] + (size_t)y * pl[p].pitch, pl[p].src + (ptrdiff_t)y * pl[p].ls, pl[p].row_bytes);
+            up[i] = hipMemcpyAsync(pl[p].dst + (size_t)y0 * pl[p].pitch, at[p] + (size_t)y0 * pl[p].pitch,
+                                   pl[p].pitch * (size_t)(y1 - y0 - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh);
+        };
+        if (r.pool) {
+            try { r.pool->run(nsl, slice); } catch (...) { return FFV2AMD_ERR_NOMEM; }
+        } else {
+            for (int i = 0; i < nsl; i++) slice(i);
         }
+        for (int i = 0; i < nsl; i++) HIPCHK(up[i]);
         HIPCHK(hipEventRecord(r.ev_bounce[k], sh));
     }
     if (is420)

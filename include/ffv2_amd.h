@@ -199,7 +199,8 @@ int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
  *                    been received: the DMA engine reads them in place), FFV2AMD_FRAME_REGISTER (the same promise for
  *                    ordinary memory from a pool of long-lived buffers, page-locked here on first sight) and/or
  *                    FFV2AMD_FRAME_YUV420 (data = Y, U, V of a yuv420p* frame); otherwise the rows are copied before
- *                    the call returns.
+ *                    the call returns (into about 256 MB of page-locked bounce frames the ring owns, by helper
+ *                    threads as in ring_send: FFV2AMD_GATHER_THREADS).
  *                    FFV2AMD_ERR_AGAIN: a batch is full, two calls are in flight and the packets of the one
  *                    before them have not all been received -- receive, then send the frame again.
  *   qpring_flush   : end of stream (avcodec_send_frame(NULL)): the partly filled batch goes out.  FFV2AMD_ERR_AGAIN

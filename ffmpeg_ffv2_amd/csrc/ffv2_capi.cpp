@@ -2716,6 +2716,9 @@ static bool host_range_registered(ffv2amd_encoder *e, const uint8_t *src, size_t
     for (const auto &g : e->ring_reg)
         if (g.base <= src && src + need <= g.base + g.bytes) return true;
     if (e->ring_reg.size() >= 256) return false;
+    // Small planes are not worth it: they are copied in microseconds, and page-locking them means page-locking bits of
+    // the C library's heap (allocations below its mmap threshold), pages they share with whatever else lives there.
+    if (need < ((size_t)256 << 10)) return false;
     if (hipHostRegister((void *)src, need, hipHostRegisterDefault) == hipSuccess) {
         try { e->ring_reg.push_back({ src, need }); return true; }
         catch (...) { (void)hipHostUnregister((void *)src); return false; }

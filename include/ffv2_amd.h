@@ -345,7 +345,8 @@ int  ffv2amd_encoder_flush(ffv2amd_encoder *enc, void *stream);
                                         time it sees it (hipHostRegister, milliseconds) and lets the DMA engine read it in place
                                         from then on, like FFV2AMD_FRAME_PINNED; same promise: untouched until the frame's packet
                                         has been received, and the buffers outlive the ring (registrations end at ring_close;
-                                        at most 256 buffers, further ones are gathered like unflagged frames) */
+                                        at most 256 buffers, further ones -- and planes below 256 KB, which would page-lock bits
+                                        of the C library's heap -- are gathered like unflagged frames) */
 int   ffv2amd_ring_open(ffv2amd_encoder *enc, int depth);
 int   ffv2amd_ring_send(ffv2amd_encoder *enc, const uint8_t *const data[4], const ptrdiff_t linesize[4],
                         const int32_t *W, int64_t tag, unsigned flags);

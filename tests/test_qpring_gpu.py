@@ -142,7 +142,7 @@ def test_qpring_arguments_and_reopen(oracle):
 def test_qpring_registers_pooled_pageable_frames(oracle):
     """FFV2AMD_FRAME_REGISTER: a pool of two ordinary buffers, refilled after their packets have come back; the ring
     page-locks each on first sight and reads it in place from then on."""
-    W_, H_, fmt, qp = 150, 100, "yuv444p", 16
+    W_, H_, fmt, qp = 960, 540, "yuv444p", 16              # planes of 506 KB: above the 256 KB below which nothing is page-locked
     enc = _enc(W_, H_, fmt)
     pool = [np.empty((3, H_, W_), np.uint8) for _ in range(2)]
     frames = [synth.noise(300 + i, 3, H_, W_, 8) for i in range(6)]

@@ -1,0 +1,30 @@
+/* LD_PRELOAD / dlopen aid (tests/conftest.py loads it when it is built): on SIGABRT print the C call stack of the thread that aborted (who called abort(): the HIP / HSA
+ * runtime, glibc's heap checks, libstdc++'s terminate ...), then die as before.  gcc -shared -fPIC -o abort_trace.so abort_trace.c */
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
+#include <string.h>
+#include <unistd.h>
+
+static struct sigaction previous;
+
+static void on_abort(int sig)
+{
+    void *buf[64];
+    static const char msg[] = "\n=== abort_trace: SIGABRT raised from ===\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    const int n = backtrace(buf, 64);
+    backtrace_symbols_fd(buf, n, 2);
+    sigaction(sig, &previous, NULL);     /* whoever was there before (Python's faulthandler, or the default) goes on from here */
+    raise(sig);
+}
+
+__attribute__((constructor)) static void install(void)
+{
+    void *warm[2];
+    backtrace(warm, 2);                 /* loads libgcc now, not inside the handler */
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_abort;
+    sigaction(SIGABRT, &sa, &previous);
+}

@@ -245,10 +245,16 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
             n_done, tcpu, ok = 0, 0.0, True
             while n_done < distinct and tcpu < args.cpu_seconds:
                 c0 = time.perf_counter()
-                ref = oracle.encode(host_frames[n_done], fmt, qp=args.qp)
+                try:
+                    ref = oracle.encode(host_frames[n_done], fmt, qp=args.qp)
+                except RuntimeError:
+                    ref = None                            # the reference would av_assert0 on this frame (daala_entropy.c:336)
                 tcpu += time.perf_counter() - c0
                 for i in range(n_done, F, distinct):      # every repetition of this frame
-                    ok = ok and status[i] == 0 and buf[int(offs[i]): int(offs[i]) + int(sizes[i])].tobytes() == ref
+                    if ref is None:
+                        ok = ok and status[i] == -1
+                    else:
+                        ok = ok and status[i] == 0 and buf[int(offs[i]): int(offs[i]) + int(sizes[i])].tobytes() == ref
                 n_done += 1
             res["cpu_baseline"] = {"value": round(n_done * W * H / tcpu / 1e6, 2), "unit": "Mpix/s", "cores": 1,
                                    "kind": "port", "sample": "%d of the %d distinct benchmark frames, oracle qp=%d, 1 thread"

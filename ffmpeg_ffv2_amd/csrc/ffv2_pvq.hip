@@ -470,6 +470,7 @@ __device__ PvqBandCount pvq_search_lists(const float (&x)[M], int N, int K, PvqL
                     const float q = __fdiv_rn(__fmul_rn(n, n), Syy);
                     if (ext == 0) pF = hasF ? __shfl(q, cls, 64) : -1.0f;
                     const unsigned long long tm = __ballot(ok && q == pF);
+                    if (ext == 0 && (tm >> 4) == 0) { tstar = 1; break; }       // the rule: no float below n(A) reaches p(A)
                     const unsigned long long cm = ~(tm >> cls) & 0x1111111111111111ull;
                     const int nt = cm ? (__ffsll((long long)cm) - 1) >> 2 : 16;
                     if (tstar < 0 && nt < 16) tstar = ext + nt;

@@ -669,8 +669,19 @@ __device__ __forceinline__ PvqBandCount quant_band_lists(const int32_t *coef, in
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) e += __shfl_xor(e, o, 64);
     const float fgain = __fadd_rn(sqrtf((float)e), 1.1920929e-7f);     // ffv2enc.c:166
+    // ffv2enc.c:169, the IEEE division by a denominator all elements share: its reciprocal and the reciprocal's
+    // refinement once, the two quotient corrections per element -- the sequence the hardware division runs, without its
+    // scaling and fix-up instructions, which do nothing here: numerators are 0 or 1 ... 2^31 in magnitude, the
+    // denominator lies in [2^-23, 2^37] and is at least as large as any numerator (same argument as in pvq_search_wave)
+    const float r0 = __builtin_amdgcn_rcpf(fgain);
+    const float r1 = __fmaf_rn(__fmaf_rn(-fgain, r0, 1.0f), r0, r0);
 #pragma unroll
-    for (int m = 0; m < M; m++) x[m] = __fdiv_rn(x[m], fgain);          // ffv2enc.c:169
+    for (int m = 0; m < M; m++) {
+        const float n = x[m];
+        const float q0 = __fmul_rn(n, r1);
+        const float q1 = __fmaf_rn(__fmaf_rn(-fgain, q0, n), r1, q0);
+        x[m] = __fmaf_rn(__fmaf_rn(-fgain, q1, n), r1, q1);
+    }
     return pvq_search_lists<M>(x, N, K, L, lane, y + lo);
 }
 

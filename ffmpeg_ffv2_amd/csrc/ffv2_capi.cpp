@@ -694,6 +694,10 @@ struct ffv2amd_encoder {
     // qp > 0 coder with many frames in flight (ffv2amd_lanecoder_*, ffv2_lanecoder.hip)
     struct LaneCoder {
         int cap = 0;                     // frames in flight per call
+        int group = 0;                   // frames per launch of the front (T-stage, PVQ search, scan, scatter): the coder's own
+        int32_t *d_coef = nullptr;       // workspaces for that many frames -- not the encoder's max_batch, which belongs to the
+        int16_t *d_y = nullptr;          // batch entry points (the codec shim creates its encoders with max_batch 1)
+        uint32_t *d_bitcnt = nullptr;
         FFV2LaneCoderArgs a{};           // geometry and the back's scratch (records, code words), sized for `cap` frames
         uint2 *d_split = nullptr;
         // the front's buffers, twice: call n+1's front runs beside call n's chain
@@ -1597,7 +1601,18 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     a.raw_words = (uint32_t)(pcap / 4 + 4);
     a.wcap = (uint32_t)(pcap / 2 + 32);
     a.packet_stride = pcap;
-    bool ok = dev(&a.recs, sizeof(uint2) * a.buf_stride * 2) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
+    {   // frames per launch of the front: up to 64, within about 2.5 GB of coefficient / pulse workspace
+        const size_t per = nb * (sizeof(int32_t) * 4096 + sizeof(int16_t) * FFV2_Y_STRIDE + sizeof(uint32_t));
+        size_t g = (((size_t)5 << 29)) / per;
+        if (g > 64) g = 64;
+        if (g < 1) g = 1;
+        if (g > F) g = F;
+        lc.group = (int)g;
+    }
+    bool ok = dev(&lc.d_coef, sizeof(int32_t) * 4096 * nb * (size_t)lc.group)
+           && dev(&lc.d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * (size_t)lc.group)
+           && dev(&lc.d_bitcnt, sizeof(uint32_t) * nb * (size_t)lc.group)
+           && dev(&a.recs, sizeof(uint2) * a.buf_stride * 2) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
            && dev(&a.cdfstate, sizeof(uint32_t) * 68 * 13 * F)
            && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.fin, sizeof(uint4) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
     for (int k = 0; k < nsets; k++) {
@@ -1790,11 +1805,7 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const ffv2amd_info &in = e->info;
-    const size_t nb = (size_t)in.block_planes, B = (size_t)in.max_batch;
-    if (!e->d_coef_ws) {
-        HIPCHK(hipMalloc(&e->d_coef_ws, sizeof(int32_t) * 4096 * nb * B));
-        HIPCHK(hipMalloc(&e->d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * B));
-    }
+    const size_t nb = (size_t)in.block_planes, B = (size_t)lc.group;
     hipStream_t s = e->stream;
     FFV2LaneCoderArgs a = lc.a;
     a.qp = qp;
@@ -1817,20 +1828,20 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
         const int n = nframes - f0 < (int)B ? nframes - f0 : (int)B;
         FFV2TStageArgs t{};
         t.g = e->geom; t.nframes = n; t.frames = (const uint8_t *)d_frames + (size_t)f0 * in.frame_stride;
-        t.coef = e->d_coef_ws; t.energy = nullptr; t.codes = q.d_codes + (size_t)f0 * nb * FFV2_CODES_PER_BP;
-        t.bitcnt = e->d_bitoff; t.W = d_W ? d_W + (size_t)f0 * nb : nullptr;
+        t.coef = lc.d_coef; t.energy = nullptr; t.codes = q.d_codes + (size_t)f0 * nb * FFV2_CODES_PER_BP;
+        t.bitcnt = lc.d_bitcnt; t.W = d_W ? d_W + (size_t)f0 * nb : nullptr;
         t.gain_thr = e->d_thr; t.gain_n = GAIN_TABLE_N; t.lds_scan = e->d_lds_scan; t.status = q.d_status_in + f0;
         HIPCHK(ffv2_launch_tstage(t, s));
         // the search also notes what the coder will read of every band (FFV2AMD_LC_COUNT_KERNEL=1: a pass of its own
         // over the pulses finds out, as before round 3; same numbers)
         const bool count_pass = getenv("FFV2AMD_LC_COUNT_KERNEL") && atoi(getenv("FFV2AMD_LC_COUNT_KERNEL")) != 0;   // read per call: tests flip it
         if (count_pass)
-            HIPCHK(ffv2_launch_pvq(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, s));
+            HIPCHK(ffv2_launch_pvq(lc.d_coef, t.W, lc.d_y, qp, (long long)nb * n, s));
         else
-            HIPCHK(ffv2_launch_pvq_counted(e->d_coef_ws, t.W, e->d_y, qp, (long long)nb * n, (int)nb, t.codes,
+            HIPCHK(ffv2_launch_pvq_counted(lc.d_coef, t.W, lc.d_y, qp, (long long)nb * n, (int)nb, t.codes,
                                            a.cnt + (size_t)f0 * nb, a.bits + (size_t)f0 * nb, a.abort_ + f0, s));
         a.f0 = f0;
-        HIPCHK(ffv2_launch_lc_front(a, e->d_y, n, !count_pass, s));
+        HIPCHK(ffv2_launch_lc_front(a, lc.d_y, n, !count_pass, s));
     }
     HIPCHK(hipEventRecord(q.ev_front, s));
     // back: cdf and chain window by window, then the packets.  One call's back runs at a time (its

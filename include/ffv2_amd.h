@@ -224,7 +224,9 @@ int  ffv2amd_qpring_close(ffv2amd_encoder *enc);
  * side, one per lane of a wavefront, and does the rest (CDF rows as prefix counts, raw bits,
  * carry propagation) data-parallel.  Throughput grows with the frames in flight until the other
  * kernels bound it; a call takes at least one frame's chain (about 73 ns per symbol).
- *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call
+ *   lanecoder_open   : sizes the HBM scratch for `frames_in_flight` frames per call (plus, once, the coder's own
+ *                      transform / pulse workspace for up to 64 frames, at most 2.5 GB: its launches do not
+ *                      depend on the encoder's max_batch)
  *                      (ffv2amd_lanecoder_bytes_per_frame() each: 38 MB per 1080p frame with the
  *                      default packet_cap and two calls in flight; round 2: 84 MB, before the range
  *                      chain's input was produced window by window);

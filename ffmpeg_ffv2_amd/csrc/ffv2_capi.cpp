@@ -736,6 +736,7 @@ struct ffv2amd_encoder {
         int32_t *d_w[3] = { nullptr, nullptr, nullptr };
         bool any_w[3] = { false, false, false };
         std::vector<int64_t> tags[3];
+        std::vector<uint8_t> is420[3];           // per frame of the batch: its chroma waits in d_c420 for the up-conversion
         int fill = 0, count = 0;                 // buffer being filled, frames in it
         int flight[2] = { -1, -1 };              // buffers of the calls in flight, oldest first
         int flight_n[2] = { 0, 0 };
@@ -2310,7 +2311,8 @@ int ffv2amd_qpring_open(ffv2amd_encoder *e, int qp, int frames_per_call, size_t 
     QK(hipEventCreateWithFlags(&r.ev_batch, hipEventDisableTiming));
     for (int i = 0; i < 3; i++) {
         QK(hipMalloc(&r.d_frames[i], in.frame_stride * (size_t)frames_per_call));
-        try { r.tags[i].assign((size_t)frames_per_call, 0); } catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
+        try { r.tags[i].assign((size_t)frames_per_call, 0); r.is420[i].assign((size_t)frames_per_call, 0); }
+        catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
     }
     r.h_cap = (size_t)frames_per_call * (r.pcap + 16);
     QK(hipHostMalloc(&r.h_buf, r.h_cap, hipHostMallocDefault));
@@ -2367,6 +2369,21 @@ static int qpring_submit(ffv2amd_encoder *e)
     HIPCHK(hipEventRecord(r.ev_batch, r.h2d));
     HIPCHK(hipStreamWaitEvent(e->stream, r.ev_batch, 0));
     const int b = r.fill;
+    {   // 4:2:0 frames of the batch: their chroma is up-converted now, one launch per run of such frames (a launch per
+        // frame on the copy stream stood in the queue behind the coder's long kernels every other run)
+        const ffv2amd_info &in = e->info;
+        const size_t bps = in.depth > 8 ? 2 : 1;
+        const int cw = (in.width + 1) >> 1, ch = (in.height + 1) >> 1;
+        const size_t c_pitch = align_up((size_t)cw * bps, 128), c_frame = 2 * c_pitch * (size_t)ch;
+        for (int i0 = 0; i0 < r.count; ) {
+            if (!r.is420[b][(size_t)i0]) { i0++; continue; }
+            int i1 = i0;
+            while (i1 < r.count && r.is420[b][(size_t)i1]) i1++;
+            HIPCHK(ffv2_launch_upconv_chroma(e->upconv, e->geom, i1 - i0, r.d_c420[b] + (size_t)i0 * c_frame, c_pitch,
+                                             c_pitch * (size_t)ch, c_frame, r.d_frames[b] + (size_t)i0 * in.frame_stride, e->stream));
+            i0 = i1;
+        }
+    }
     const int rc = ffv2amd_lanecoder_submit(e, r.count, r.d_frames[b], r.qp, r.any_w[b] ? r.d_w[b] : nullptr);
     if (rc < 0) return rc;
     r.flight[r.nflight] = b; r.flight_n[r.nflight] = r.count; r.nflight++;
@@ -2470,8 +2487,7 @@ int ffv2amd_qpring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const 
         for (int i = 0; i < nsl; i++) HIPCHK(up[i]);
         HIPCHK(hipEventRecord(r.ev_bounce[k], sh));
     }
-    if (is420)
-        HIPCHK(ffv2_launch_upconv_chroma(e->upconv, e->geom, 1, d_c, c_pitch, c_pitch * (size_t)ch, 0, d_frame, sh));
+    r.is420[b][(size_t)r.count] = is420 ? 1 : 0;                 // up-converted when the batch leaves (qpring_submit)
     if (W) {
         if (!r.d_w[b]) HIPCHK(hipMalloc(&r.d_w[b], sizeof(int32_t) * nb * (size_t)r.cap));
         if (!r.any_w[b]) {

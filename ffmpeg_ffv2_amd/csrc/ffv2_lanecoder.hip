@@ -355,8 +355,13 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
     uint32_t gF = F0, gk = k0, gm = m;           // the next chunk to ask for (wave-uniform, runs ahead of F0 / k0 / m)
     bool gh = halve;
     uint32_t xcur[LC_GROUP], xnext[LC_GROUP];
+    // total / position / length / "halves the row" of this group's chunks and the next group's: worked out once, where
+    // their symbols are asked for (the scalar unit has as much to do in this kernel as the vector units)
+    uint32_t cF[LC_GROUP + 1], ck[LC_GROUP + 1], cm[LC_GROUP], nF[LC_GROUP], nk[LC_GROUP], nm[LC_GROUP];
+    bool chv[LC_GROUP], nhv[LC_GROUP];
 #pragma unroll
     for (int j = 0; j < LC_GROUP; j++) {
+        cF[j] = gF; ck[j] = gk; cm[j] = gm; chv[j] = gh;
         xcur[j] = fetch(gk);
         next_chunk(gF, gk, gm, gh, &gF, &gk, &gm, &gh);
     }
@@ -373,17 +378,18 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
         for (int j = 0; j < LC_GROUP; j++) send(poff[j], prec[j]);
 #pragma unroll
         for (int j = 0; j < LC_GROUP; j++) {
+            nF[j] = gF; nk[j] = gk; nm[j] = gm; nhv[j] = gh;
             xnext[j] = fetch(gk);
             next_chunk(gF, gk, gm, gh, &gF, &gk, &gm, &gh);
             coff[j] = NOREC; crec[j] = make_uint2(0u, 0u);
         }
+        cF[LC_GROUP] = nF[0]; ck[LC_GROUP] = nk[0];            // what follows the group's last chunk
 #pragma unroll
         for (int j = 0; j < LC_GROUP; j++) {
             if (!(k0 < L)) { done = true; break; }
-            uint32_t F1 = halve ? ((F0 + 64u * (m - 1u)) >> 1) + (uint32_t)n + 64u : F0 + 64u * m;
-            uint32_t k1 = k0 + m;
-            bool halve1 = false;
-            const uint32_t m1 = k1 < L ? chunk_len(F1, k1, &halve1) : 0u;
+            m = cm[j]; halve = chv[j];                          // (F0, k0) == (cF[j], ck[j])
+            uint32_t F1 = cF[j + 1];
+            uint32_t k1 = ck[j + 1];
 
             // which block-plane a symbol belongs to.  Usually the whole chunk lies inside the current
             // block-plane's band; otherwise the band ends inside this chunk become flags in LDS and a
@@ -471,10 +477,12 @@ __global__ __launch_bounds__(64) void lc_cdf_kernel(const FFV2LaneCoderArgs a)
             else R += 64u * ca;
             F0 = F1; k0 = k1;
             if (last_chunk) { done = true; break; }
-            m = m1; halve = halve1;
         }
 #pragma unroll
-        for (int j = 0; j < LC_GROUP; j++) { xcur[j] = xnext[j]; poff[j] = coff[j]; prec[j] = crec[j]; }
+        for (int j = 0; j < LC_GROUP; j++) {
+            xcur[j] = xnext[j]; poff[j] = coff[j]; prec[j] = crec[j];
+            cF[j] = nF[j]; ck[j] = nk[j]; cm[j] = nm[j]; chv[j] = nhv[j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < LC_GROUP; j++) send(poff[j], prec[j]);

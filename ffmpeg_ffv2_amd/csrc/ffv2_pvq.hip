@@ -40,6 +40,31 @@ __device__ __forceinline__ float hsum4(float c0, float c1, float c2, float c3)  
     return __fadd_rn(__fadd_rn(c0, c2), __fadd_rn(c1, c3));
 }
 
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+// over the 16 lanes of a class (lane & 3): every lane ends up with its class's value
+__device__ __forceinline__ int class_max_i32(int v)
+{
+    int t = dpp_mov<0x124>(v); v = t > v ? t : v;              // row_ror:4
+    t = dpp_mov<0x128>(v); v = t > v ? t : v;                  // row_ror:8
+    t = __shfl_xor(v, 16, 64); v = t > v ? t : v;
+    t = __shfl_xor(v, 32, 64); v = t > v ? t : v;
+    return v;
+}
+
+__device__ __forceinline__ int class_min_i32(int v)
+{
+    int t = dpp_mov<0x124>(v); v = t < v ? t : v;
+    t = dpp_mov<0x128>(v); v = t < v ? t : v;
+    t = __shfl_xor(v, 16, 64); v = t < v ? t : v;
+    t = __shfl_xor(v, 32, 64); v = t < v ? t : v;
+    return v;
+}
+
 // What the range coder will do with a band (ffv2enc.c:175-186): it reads pulses until their magnitudes add
 // up to qp (`stop` symbols, all N if they never do), appends a sign bit for each non-zero one (`nz`), and
 // asserts when a magnitude reaches the alphabet size (daala_entropy.c:336; `big`).  Wave-uniform.
@@ -194,22 +219,37 @@ __device__ PvqBandCount pvq_search_wave(const float (&x)[M], int N, int K, PvqLd
                     if (i < N4 && bp < pp) { bp = pp; bi = i; }
                 }
             }
-            // same class across lanes (lane ^ 4, 8, 16, 32): larger p, then lower index
+            int best;
+            if (add && tame) {
+                // p >= 0 here (-1 beyond N4), ordered like its bit pattern: the class's largest p by an integer maximum,
+                // the lowest index that has it by a minimum, the four classes merged on scalars
+                const int pm = class_max_i32(__float_as_int(bp));
+                const int im = class_min_i32(__float_as_int(bp) == pm && bp >= 0.0f ? bi : 0x7fffffff);
+                float q0 = __int_as_float(__builtin_amdgcn_readlane(pm, 0)), q1 = __int_as_float(__builtin_amdgcn_readlane(pm, 1));
+                const float q2 = __int_as_float(__builtin_amdgcn_readlane(pm, 2)), q3 = __int_as_float(__builtin_amdgcn_readlane(pm, 3));
+                int i0 = __builtin_amdgcn_readlane(im, 0), i1 = __builtin_amdgcn_readlane(im, 1);
+                const int i2 = __builtin_amdgcn_readlane(im, 2), i3 = __builtin_amdgcn_readlane(im, 3);
+                if (q0 < q2) { q0 = q2; i0 = i2; }            // classes (3,2) replace (1,0) only when strictly greater
+                if (q1 < q3) { q1 = q3; i1 = i3; }
+                best = !(q1 < q0) ? i1 : i0;                  // class 1 replaces class 0 unless p1 < p0 (cmpss predicate 5 = NLT)
+            } else {
+                // same class across lanes (lane ^ 4, 8, 16, 32): larger p, then lower index
 #pragma unroll
-            for (int o = 4; o <= 32; o <<= 1) {
-                const float op = __shfl_xor(bp, o, 64);
-                const int oi = __shfl_xor(bi, o, 64);
-                if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
+                for (int o = 4; o <= 32; o <<= 1) {
+                    const float op = __shfl_xor(bp, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (op > bp || (op == bp && oi < bi)) { bp = op; bi = oi; }
+                }
+                {   // classes (3,2) replace (1,0) only when strictly greater
+                    const float op = __shfl_xor(bp, 2, 64);
+                    const int oi = __shfl_xor(bi, 2, 64);
+                    if ((lane & 2) == 0 && bp < op) { bp = op; bi = oi; }
+                }
+                // class 1 replaces class 0 unless p1 < p0 (cmpss predicate 5 = NLT)
+                const float p1 = __shfl(bp, 1, 64), p0 = __shfl(bp, 0, 64);
+                const int i1 = __shfl(bi, 1, 64), i0 = __shfl(bi, 0, 64);
+                best = !(p1 < p0) ? i1 : i0;
             }
-            {   // classes (3,2) replace (1,0) only when strictly greater
-                const float op = __shfl_xor(bp, 2, 64);
-                const int oi = __shfl_xor(bi, 2, 64);
-                if ((lane & 2) == 0 && bp < op) { bp = op; bi = oi; }
-            }
-            // class 1 replaces class 0 unless p1 < p0 (cmpss predicate 5 = NLT)
-            const float p1 = __shfl(bp, 1, 64), p0 = __shfl(bp, 0, 64);
-            const int i1 = __shfl(bi, 1, 64), i0 = __shfl(bi, 0, 64);
-            const int best = !(p1 < p0) ? i1 : i0;
             // the winner's |x| and pulse count live in its owner's registers: the owner (lane
             // best & 63) picks them out, one lane read hands them round -- no LDS, no barrier
             float axb = 0.0f, fyb = 0.0f;
@@ -271,31 +311,6 @@ __device__ PvqBandCount pvq_search_wave(const float (&x)[M], int N, int K, PvqLd
 // Exact for what ffv2_pvq_kernel feeds it (0 or 2^-40 <= |x| <= 2^40, K <= 64); the test hook routes
 // anything else to pvq_search_wave.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-
-// over the 16 lanes of a class (lane & 3): every lane ends up with its class's value
-__device__ __forceinline__ int class_max_i32(int v)
-{
-    int t = dpp_mov<0x124>(v); v = t > v ? t : v;              // row_ror:4
-    t = dpp_mov<0x128>(v); v = t > v ? t : v;                  // row_ror:8
-    t = __shfl_xor(v, 16, 64); v = t > v ? t : v;
-    t = __shfl_xor(v, 32, 64); v = t > v ? t : v;
-    return v;
-}
-
-__device__ __forceinline__ int class_min_i32(int v)
-{
-    int t = dpp_mov<0x124>(v); v = t < v ? t : v;
-    t = dpp_mov<0x128>(v); v = t < v ? t : v;
-    t = __shfl_xor(v, 16, 64); v = t < v ? t : v;
-    t = __shfl_xor(v, 32, 64); v = t < v ? t : v;
-    return v;
-}
-
 // the list: up to PVQ_LIST_E entries per lane, in the staging buffer of the sums once they are done
 constexpr int PVQ_LIST_E = 8;                  // 16 entries per class and row: 128 per class >= 2 K for K <= 64
 struct PvqList {

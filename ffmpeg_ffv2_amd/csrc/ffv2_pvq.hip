@@ -501,7 +501,9 @@ __device__ PvqBandCount pvq_search_lists(const float (&x)[M], int N, int K, PvqL
                     const int ci = Q.idx[k][lane];
                     const float num = __fadd_rn(fabsf(Q.x[k][lane]), Sxy);
                     const float pc = __fdiv_rn(__fmul_rn(num, num), __fadd_rn(Q.fy[k][lane], Syy));
-                    if (ci >= 0 && (pc > p || (pc == p && ci < idx))) { p = pc; idx = ci; }
+                    const bool better = (ci >= 0) & ((pc > p) | ((pc == p) & (ci < idx)));     // selects, no branches
+                    p = better ? pc : p;
+                    idx = better ? ci : idx;
                 }
                 // the class's largest p (p >= 0, or -1 for "nothing": ordered like the bit patterns), lowest index
                 const int pm = class_max_i32(__float_as_int(p));

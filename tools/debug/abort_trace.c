@@ -7,14 +7,16 @@
 #include <unistd.h>
 
 static struct sigaction previous;
+static int out_fd = 2;                 /* a copy of stderr as it was when this was loaded: pytest points fd 2 at a capture file
+                                          while a test runs, and what is written there dies with the process */
 
 static void on_abort(int sig)
 {
     void *buf[64];
     static const char msg[] = "\n=== abort_trace: SIGABRT raised from ===\n";
-    (void)!write(2, msg, sizeof(msg) - 1);
+    (void)!write(out_fd, msg, sizeof(msg) - 1);
     const int n = backtrace(buf, 64);
-    backtrace_symbols_fd(buf, n, 2);
+    backtrace_symbols_fd(buf, n, out_fd);
     sigaction(sig, &previous, NULL);     /* whoever was there before (Python's faulthandler, or the default) goes on from here */
     raise(sig);
 }
@@ -22,6 +24,8 @@ static void on_abort(int sig)
 __attribute__((constructor)) static void install(void)
 {
     void *warm[2];
+    const int fd = dup(2);
+    if (fd >= 0) out_fd = fd;
     backtrace(warm, 2);                 /* loads libgcc now, not inside the handler */
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));

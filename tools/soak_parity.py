@@ -28,6 +28,7 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
     lib = _lib.load()
     rng = np.random.default_rng(seed)
     t0, n, nq, n420 = time.time(), 0, 0, 0
+    trace = os.environ.get("FFV2_SOAK_TRACE")
     nwide = ndec = 0
     try:
         while (cases is None or n < cases) and (cases is not None or time.time() - t0 < budget):
@@ -38,6 +39,9 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
             F = int(rng.integers(1, 4))
             mode = int(rng.integers(0, 2))
             lib.ffv2amd_debug_force_tstage(mode)
+            if trace:                                  # survives a process that dies: the case it died in
+                with open(trace, "w") as tf:
+                    tf.write("case %d: %s %dx%d, %d frames, forced T-stage kernel %d\n" % (n, fmt, W, H, F, mode))
             enc = FFV2Encoder(W, H, fmt, device=0, max_batch=F)
             kinds = ["S1", "S2", "flat"]
             frames = []

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <unistd.h>
 
+char abort_trace_note[256];             /* whoever loaded this may leave a line here (what it was doing): printed with the stack */
 static struct sigaction previous;
 static int out_fd = 2;                 /* a copy of stderr as it was when this was loaded: pytest points fd 2 at a capture file
                                           while a test runs, and what is written there dies with the process */
@@ -15,6 +16,10 @@ static void on_abort(int sig)
     void *buf[64];
     static const char msg[] = "\n=== abort_trace: SIGABRT raised from ===\n";
     (void)!write(out_fd, msg, sizeof(msg) - 1);
+    if (abort_trace_note[0]) {
+        (void)!write(out_fd, abort_trace_note, strnlen(abort_trace_note, sizeof(abort_trace_note)));
+        (void)!write(out_fd, "\n", 1);
+    }
     const int n = backtrace(buf, 64);
     backtrace_symbols_fd(buf, n, out_fd);
     sigaction(sig, &previous, NULL);     /* whoever was there before (Python's faulthandler, or the default) goes on from here */

@@ -29,6 +29,14 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
     rng = np.random.default_rng(seed)
     t0, n, nq, n420 = time.time(), 0, 0, 0
     trace = os.environ.get("FFV2_SOAK_TRACE")
+    note = None                                        # the abort tracer (tools/debug/abort_trace.c) prints it if the process dies
+    try:
+        import ctypes
+        so = os.path.join(ROOT, "tools", "debug", "abort_trace.so")
+        if os.path.exists(so):
+            note = (ctypes.c_char * 256).in_dll(ctypes.CDLL(so), "abort_trace_note")
+    except (OSError, ValueError):
+        note = None
     nwide = ndec = 0
     try:
         while (cases is None or n < cases) and (cases is not None or time.time() - t0 < budget):
@@ -39,6 +47,8 @@ def run(budget=120.0, seed=2024, cases=None, max_w=900, max_h=700, p_qp=0.15, p_
             F = int(rng.integers(1, 4))
             mode = int(rng.integers(0, 2))
             lib.ffv2amd_debug_force_tstage(mode)
+            if note is not None:
+                note.value = ("soak_parity case %d: %s %dx%d, %d frames, forced T-stage kernel %d" % (n, fmt, W, H, F, mode)).encode()[:255]
             if trace:                                  # survives a process that dies: the case it died in
                 with open(trace, "w") as tf:
                     tf.write("case %d: %s %dx%d, %d frames, forced T-stage kernel %d\n" % (n, fmt, W, H, F, mode))

@@ -22,6 +22,19 @@ static void on_abort(int sig)
     }
     const int n = backtrace(buf, 64);
     backtrace_symbols_fd(buf, n, out_fd);
+    /* what the aborting library said before it called abort(): if fd 2 is a capture file now, its last 2 KB */
+    const off_t end = lseek(2, 0, SEEK_CUR);
+    if (end > 0) {
+        static char tail[2048];
+        const off_t from = end > (off_t)sizeof(tail) ? end - (off_t)sizeof(tail) : 0;
+        const ssize_t got = pread(2, tail, (size_t)(end - from), from);
+        if (got > 0) {
+            static const char hdr[] = "=== abort_trace: the end of the captured stderr ===\n";
+            (void)!write(out_fd, hdr, sizeof(hdr) - 1);
+            (void)!write(out_fd, tail, (size_t)got);
+            (void)!write(out_fd, "\n", 1);
+        }
+    }
     sigaction(sig, &previous, NULL);     /* whoever was there before (Python's faulthandler, or the default) goes on from here */
     raise(sig);
 }

@@ -144,7 +144,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
     from ffmpeg_ffv2_amd._lib import FFV2Error
     while True:                                   # fewer frames in flight if the device cannot hold the scratch
         try:
-            enc.lanecoder_open(F, args.packet_cap, args.calls_in_flight)
+            enc.lanecoder_open(F, args.packet_cap, args.calls_in_flight, args.backs)
             break
         except FFV2Error as ex:
             if ex.code != -12 or F <= 64:
@@ -190,8 +190,8 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                                       "frames resident in HBM, packets to host memory" % (W, H, fmt, args.qp, F, distinct),
                           "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
                           "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
-                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight) / 1e9, 1),
-                          "calls_in_flight": args.calls_in_flight,
+                          "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight, args.backs) / 1e9, 1),
+                          "calls_in_flight": args.calls_in_flight, "range_chains_side_by_side": args.backs,
                           "packet_cap": args.packet_cap or enc.info.packet_cap_qp,
                           "packets_out": "one copy per packet" if args.strided_packets else "packed, one copy"},
                "chain": dict(zip(("kernel", "ms", "back_ms", "symbols_frame0", "ns_per_symbol", "what"),
@@ -278,7 +278,9 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
     W, H = i.width, i.height
     # a call lasts at least one frame's range chain (0.6 s for 1080p noise at qp 16) whatever it holds: large batches
     per_call = max(64, min(F // 2, 4096) // 64 * 64)
-    total = 8 * per_call                         # filling and draining the pipeline included
+    if args.host_frames_per_call > 0:
+        per_call = args.host_frames_per_call
+    total = max(8 * per_call, min(16384, 32 * per_call))     # filling and draining the pipeline included
     nsrc = host_frames.shape[0]
     out = {"frames_per_call": per_call, "frames_sent": total, "what":
            "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
@@ -374,6 +376,9 @@ def main():
     ap.add_argument("--no-preroll", action="store_true", help="skip the untimed clock-settling pre-roll")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-frames-in / host-packets-out phase")
     ap.add_argument("--host-frames", type=int, default=48, help="frames per rank in the host-boundary phase")
+    ap.add_argument("--host-frames-per-call", type=int, default=0,
+                    help="with --qp on the device coder: frames per lane coder call in the host-boundary phase "
+                         "(default: half the frames in flight, at most 4096)")
     ap.add_argument("--ring-depth", type=int, default=4)
     ap.add_argument("--steady-seconds", type=float, default=2.0,
                     help="untimed steady-state loops after the timed region (0 = skip)")
@@ -386,9 +391,12 @@ def main():
     ap.add_argument("--strided-packets", action="store_true",
                     help="with --frames-in-flight: packets come back one copy each into a [frames][stride] array "
                          "(ffv2amd_lanecoder_finish) instead of packed in one copy (ffv2amd_lanecoder_finish_packed)")
-    ap.add_argument("--calls-in-flight", type=int, default=2, choices=(2, 3),
+    ap.add_argument("--calls-in-flight", type=int, default=2, choices=(2, 3, 4),
                     help="with --qp on the device coder: submitted calls before a finish is due (each holds its own copy of "
                          "the front's buffers)")
+    ap.add_argument("--backs", type=int, default=None, choices=(1, 2, 3, 4),
+                    help="with --qp on the device coder: range chains side by side (ffv2amd_lanecoder_open_ex; at most "
+                         "--calls-in-flight; default: the library's)")
     ap.add_argument("--packet-cap", type=int, default=0,
                     help="with --frames-in-flight: bytes of HBM reserved per packet (0 = the encoder's bound for any qp)")
     ap.add_argument("--qp", type=int, default=0,
@@ -401,7 +409,7 @@ def main():
         args.warmup = 1 if lane_mode else 50
 
     # before the HIP runtime initialises (and inherited by the ranks started below): see ffmpeg_ffv2_amd/_lib.py
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -458,7 +466,7 @@ def main():
         if args.frames_in_flight <= 0:
             if not args.packet_cap:
                 args.packet_cap = 4096 + 700 * enc.info.block_planes      # noise at qp 16 / 64 codes to 160 / 370 B per block-plane
-            per = enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight)
+            per = enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight, args.backs)
             args.frames_in_flight = max(64, min(8192, int(160e9 // per) // 64 * 64))
         lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
         return

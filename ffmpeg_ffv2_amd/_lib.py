@@ -6,7 +6,7 @@ import os
 # More hardware queues than the runtime's default of 4: the ring uses five streams, the lane coder four, and
 # streams that share a queue wait for each other's kernels (ffv2_capi.cpp, ffv2amd_encoder_create).  Read by
 # the HIP runtime when it initialises, so it has to be in the environment before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(PKG, "libffv2amd.so")
@@ -22,7 +22,8 @@ EXPORTS = [
     "ffv2amd_ring_send_420", "ffv2amd_tstage_wide_device", "ffv2amd_decode_frame", "ffv2amd_parse_packet", "ffv2amd_qp_send_frame", "ffv2amd_qp_send_frame_420", "ffv2amd_qp_receive_packet", "ffv2amd_qp_pending", "ffv2amd_encoder_set_device_coder",
     "ffv2amd_qpring_open", "ffv2amd_qpring_send", "ffv2amd_qpring_flush", "ffv2amd_qpring_receive", "ffv2amd_qpring_pending", "ffv2amd_qpring_close",
     "ffv2amd_frame_bytes_420", "ffv2amd_upconvert_420_device", "ffv2amd_encode_frame_420",
-    "ffv2amd_lanecoder_open", "ffv2amd_lanecoder_close", "ffv2amd_lanecoder_bytes_per_frame", "ffv2amd_lanecoder_encode",
+    "ffv2amd_lanecoder_open", "ffv2amd_lanecoder_open_ex", "ffv2amd_lanecoder_close", "ffv2amd_lanecoder_bytes_per_frame",
+    "ffv2amd_lanecoder_bytes_per_frame_ex", "ffv2amd_lanecoder_encode",
     "ffv2amd_lanecoder_submit", "ffv2amd_lanecoder_finish", "ffv2amd_lanecoder_finish_packed", "ffv2amd_lanecoder_stats", "ffv2amd_debug_lanecoder_window", "ffv2amd_debug_pvq_time",
     # AVCodec-shaped host shim (ffv2enc_amd.c)
     "ffv2amd_codec_init", "ffv2amd_codec_encode2", "ffv2amd_codec_close", "ffv2amd_codec_descriptor",
@@ -131,6 +132,9 @@ def load():
     lib.ffv2amd_lanecoder_close.argtypes = [C.c_void_p]
     lib.ffv2amd_lanecoder_bytes_per_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     lib.ffv2amd_lanecoder_bytes_per_frame.restype = C.c_size_t
+    lib.ffv2amd_lanecoder_open_ex.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    lib.ffv2amd_lanecoder_bytes_per_frame_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    lib.ffv2amd_lanecoder_bytes_per_frame_ex.restype = C.c_size_t
     lib.ffv2amd_lanecoder_submit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.ffv2amd_lanecoder_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.ffv2amd_lanecoder_finish_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -698,7 +698,7 @@ struct ffv2amd_encoder {
         int32_t *d_coef = nullptr;       // workspaces for that many frames -- not the encoder's max_batch, which belongs to the
         int16_t *d_y = nullptr;          // batch entry points (the codec shim creates its encoders with max_batch 1)
         uint32_t *d_bitcnt = nullptr;
-        FFV2LaneCoderArgs a{};           // geometry and the back's scratch (records, code words), sized for `cap` frames
+        FFV2LaneCoderArgs a{};           // geometry; the scratch pointers are filled in per call from its Set and its Back
         uint2 *d_split = nullptr;
         // the front's buffers, twice: call n+1's front runs beside call n's chain
         struct Set {
@@ -714,12 +714,25 @@ struct ffv2amd_encoder {
             hipEvent_t ev_back0 = nullptr, ev_chain0 = nullptr, ev_chain1 = nullptr;   // timing: back begins, chain begins / ends
             int nframes = 0;
             bool busy = false;
-        } set[3];
-        int nsets = 2;                   // calls in flight (2 or 3): how many of the sets are in use
-        hipStream_t back = nullptr, copy = nullptr, cdfs = nullptr;       // chain + finish | packets out | cdf windows
-        hipEvent_t ev_cdf[2] = { nullptr, nullptr }, ev_chain[2] = { nullptr, nullptr };   // per record buffer: filled / read
-        hipEvent_t ev_backdone = nullptr;                                   // the previous call's back has let go of the shared scratch
-        bool backdone_valid = false;
+        } set[4];
+        int nsets = 2;                   // calls in flight (2 to 4): how many of the sets are in use
+        // the back's scratch (records of two windows, code words, the lanes' state) and its streams.  One of them: one
+        // call's chain at a time, the next call's front beside it.  Two or more: call n takes back n % nback, so that
+        // many chains run side by side -- what a call costs is its chain's latency (one frame's symbols, whatever the
+        // call holds), and where the memory holds too few frames to cover it with the next call's front (large pictures)
+        // the second chain does.
+        struct Back {
+            uint2 *recs = nullptr;
+            uint32_t *words = nullptr, *cdfstate = nullptr;
+            FFV2LaneState *state = nullptr;
+            uint4 *fin = nullptr;
+            hipStream_t back = nullptr, cdfs = nullptr;                          // chain + finish | cdf windows
+            hipEvent_t ev_cdf[2] = { nullptr, nullptr }, ev_chain[2] = { nullptr, nullptr };   // per record buffer: filled / read
+            hipEvent_t ev_backdone = nullptr;                                    // the previous call here has let go of the scratch
+            bool backdone_valid = false;
+        } bk[4];
+        int nback = 1;
+        hipStream_t copy = nullptr;      // packets out
         uint32_t maxsym16 = 0, window = 0;                                  // symbols per frame at most; symbols per window
         unsigned sub = 0, fin = 0;
         float last_chain_ms = 0, last_back_ms = 0;   // of the call finished last (ffv2amd_lanecoder_stats)
@@ -731,15 +744,17 @@ struct ffv2amd_encoder {
     struct QpRing {
         int qp = 0, cap = 0;                     // frames per batch (= per lane coder call)
         size_t pcap = 0;
-        uint8_t *d_frames[3] = { nullptr, nullptr, nullptr };     // a batch being filled + two in flight
-        uint8_t *d_c420[3] = { nullptr, nullptr, nullptr };      // 4:2:0 chroma as it arrives: [cap][U plane, V plane]
-        int32_t *d_w[3] = { nullptr, nullptr, nullptr };
-        bool any_w[3] = { false, false, false };
-        std::vector<int64_t> tags[3];
-        std::vector<uint8_t> is420[3];           // per frame of the batch: its chroma waits in d_c420 for the up-conversion
+        static constexpr int NBUF = 5;           // a batch being filled + up to four in flight (`calls` of them in use, + 1)
+        int calls = 2;                           // lane coder calls in flight
+        uint8_t *d_frames[NBUF] = {};
+        uint8_t *d_c420[NBUF] = {};              // 4:2:0 chroma as it arrives: [cap][U plane, V plane]
+        int32_t *d_w[NBUF] = {};
+        bool any_w[NBUF] = {};
+        std::vector<int64_t> tags[NBUF];
+        std::vector<uint8_t> is420[NBUF];        // per frame of the batch: its chroma waits in d_c420 for the up-conversion
         int fill = 0, count = 0;                 // buffer being filled, frames in it
-        int flight[2] = { -1, -1 };              // buffers of the calls in flight, oldest first
-        int flight_n[2] = { 0, 0 };
+        int flight[4] = { -1, -1, -1, -1 };      // buffers of the calls in flight, oldest first
+        int flight_n[4] = { 0, 0, 0, 0 };
         int nflight = 0;
         hipStream_t h2d = nullptr;
         hipEvent_t ev_batch = nullptr;
@@ -905,7 +920,7 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     // other's kernels (measured, round 3: pageable 4:2:0 frames through the ring 12.1 -> 16.1 Gpix/s, the
     // lane coder 5.7 -> 7.0 Gpix/s with 8 queues).  The variable is read when the runtime initialises, so
     // this only helps a process whose first HIP call is ours; others set it themselves.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
         fprintf(stderr, "ffv2amd: no usable HIP device %d (found %d) -- this library has no CPU path\n", device, ndev);
@@ -1566,7 +1581,7 @@ static uint32_t lanecoder_window(size_t maxsym16)
     return (uint32_t)w;
 }
 
-static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nsets)
+static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nsets, int nback)
 {
     auto &lc = e->lc;
     const ffv2amd_info &in = e->info;
@@ -1577,7 +1592,7 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
         return true;
     };
     FFV2LaneCoderArgs &a = lc.a;
-    lc.nsets = nsets;
+    lc.nsets = nsets; lc.nback = nback;
     a.nblk = (int)nb; a.planes = in.planes;
     // Frames (lanes) per chain workgroup: as few as give about 256 workgroups (at most 333), 4 to 64.  A chain step is
     // shorter with few active lanes (20.2 -> 16.8 ms per window of 1 024 1080p frames from 64 lanes to 4), the chip has
@@ -1612,10 +1627,13 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
     }
     bool ok = dev(&lc.d_coef, sizeof(int32_t) * 4096 * nb * (size_t)lc.group)
            && dev(&lc.d_y, sizeof(int16_t) * FFV2_Y_STRIDE * nb * (size_t)lc.group)
-           && dev(&lc.d_bitcnt, sizeof(uint32_t) * nb * (size_t)lc.group)
-           && dev(&a.recs, sizeof(uint2) * a.buf_stride * 2) && dev(&a.words, sizeof(uint32_t) * a.wcap * F)
-           && dev(&a.cdfstate, sizeof(uint32_t) * 68 * 13 * F)
-           && dev(&a.state, sizeof(FFV2LaneState) * F) && dev(&a.fin, sizeof(uint4) * F) && dev(&lc.d_split, sizeof(uint2) * nsb);
+           && dev(&lc.d_bitcnt, sizeof(uint32_t) * nb * (size_t)lc.group) && dev(&lc.d_split, sizeof(uint2) * nsb);
+    for (int k = 0; k < nback; k++) {
+        auto &b = lc.bk[k];
+        ok = ok && dev(&b.recs, sizeof(uint2) * a.buf_stride * 2) && dev(&b.words, sizeof(uint32_t) * a.wcap * F)
+           && dev(&b.cdfstate, sizeof(uint32_t) * 68 * 13 * F)
+           && dev(&b.state, sizeof(FFV2LaneState) * F) && dev(&b.fin, sizeof(uint4) * F);
+    }
     for (int k = 0; k < nsets; k++) {
         auto &q = lc.set[k];
         ok = ok && dev(&q.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb * F)
@@ -1640,14 +1658,17 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
         HIPCHK(hipEventCreate(&q.ev_chain0));
         HIPCHK(hipEventCreate(&q.ev_chain1));
     }
-    HIPCHK(hipStreamCreateWithFlags(&lc.back, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&lc.copy, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&lc.cdfs, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(hipEventCreateWithFlags(&lc.ev_cdf[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&lc.ev_chain[k], hipEventDisableTiming));
+    for (int j = 0; j < nback; j++) {
+        auto &b = lc.bk[j];
+        HIPCHK(hipStreamCreateWithFlags(&b.back, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b.cdfs, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipEventCreateWithFlags(&b.ev_cdf[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b.ev_chain[k], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&b.ev_backdone, hipEventDisableTiming));
     }
-    HIPCHK(hipEventCreateWithFlags(&lc.ev_backdone, hipEventDisableTiming));
     // the symbols that carry no data: "no split" of every superblock (ffv2enc.c:222; the CDF of
     // daala_entropy.h:140-161 advances by itself), the range-coded part of the header (ffv2enc.c:449)
     std::vector<uint2> split;
@@ -1672,14 +1693,16 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
 static void lanecoder_free(ffv2amd_encoder *e)
 {
     auto &lc = e->lc;
-    if (lc.back) { (void)hipStreamSynchronize(lc.back); (void)hipStreamDestroy(lc.back); }
-    if (lc.copy) { (void)hipStreamSynchronize(lc.copy); (void)hipStreamDestroy(lc.copy); }
-    if (lc.cdfs) { (void)hipStreamSynchronize(lc.cdfs); (void)hipStreamDestroy(lc.cdfs); }
-    for (int k = 0; k < 2; k++) {
-        if (lc.ev_cdf[k]) (void)hipEventDestroy(lc.ev_cdf[k]);
-        if (lc.ev_chain[k]) (void)hipEventDestroy(lc.ev_chain[k]);
+    for (auto &b : lc.bk) {
+        if (b.back) { (void)hipStreamSynchronize(b.back); (void)hipStreamDestroy(b.back); }
+        if (b.cdfs) { (void)hipStreamSynchronize(b.cdfs); (void)hipStreamDestroy(b.cdfs); }
+        for (int k = 0; k < 2; k++) {
+            if (b.ev_cdf[k]) (void)hipEventDestroy(b.ev_cdf[k]);
+            if (b.ev_chain[k]) (void)hipEventDestroy(b.ev_chain[k]);
+        }
+        if (b.ev_backdone) (void)hipEventDestroy(b.ev_backdone);
     }
-    if (lc.ev_backdone) (void)hipEventDestroy(lc.ev_backdone);
+    if (lc.copy) { (void)hipStreamSynchronize(lc.copy); (void)hipStreamDestroy(lc.copy); }
     for (void *p : lc.allocs) (void)hipFree(p);
     lc.allocs.clear();
     for (auto &q : lc.set) {
@@ -1695,11 +1718,26 @@ static void lanecoder_free(ffv2amd_encoder *e)
     lc = ffv2amd_encoder::LaneCoder{};
 }
 
+static int lanecoder_default_backs(int calls_in_flight)
+{
+    const int env = getenv("FFV2AMD_LC_BACKS") ? atoi(getenv("FFV2AMD_LC_BACKS")) : 0;
+    const int b = env >= 1 ? env : 1;
+    return b > calls_in_flight ? calls_in_flight : b;
+}
+
 int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t packet_cap, int calls_in_flight)
+{
+    if (calls_in_flight == 0) calls_in_flight = 2;
+    return ffv2amd_lanecoder_open_ex(e, frames_in_flight, packet_cap, calls_in_flight, lanecoder_default_backs(calls_in_flight));
+}
+
+int ffv2amd_lanecoder_open_ex(ffv2amd_encoder *e, int frames_in_flight, size_t packet_cap, int calls_in_flight, int backs)
 {
     if (!e || frames_in_flight < 1 || frames_in_flight > (1 << 20)) return FFV2AMD_ERR_INVAL;
     if (calls_in_flight == 0) calls_in_flight = 2;
-    if (calls_in_flight < 2 || calls_in_flight > 3) return FFV2AMD_ERR_INVAL;
+    if (calls_in_flight < 2 || calls_in_flight > 4) return FFV2AMD_ERR_INVAL;
+    if (backs == 0) backs = 1;
+    if (backs < 1 || backs > calls_in_flight) return FFV2AMD_ERR_INVAL;
     if (packet_cap == 0 || packet_cap > e->info.packet_cap_qp) packet_cap = e->info.packet_cap_qp;
     if (packet_cap < 64) return FFV2AMD_ERR_INVAL;
     packet_cap = (packet_cap + 15) / 16 * 16;
@@ -1709,7 +1747,7 @@ int ffv2amd_lanecoder_open(ffv2amd_encoder *e, int frames_in_flight, size_t pack
         HIPCHK(hipStreamSynchronize(e->stream));
         lanecoder_free(e);
     }
-    const int r = lanecoder_alloc(e, frames_in_flight, packet_cap, calls_in_flight);
+    const int r = lanecoder_alloc(e, frames_in_flight, packet_cap, calls_in_flight, backs);
     if (r < 0) {
         lanecoder_free(e);
         (void)hipGetLastError();                                  // a refused hipMalloc must not surface in the next launch check
@@ -1764,7 +1802,17 @@ int ffv2amd_lanecoder_close(ffv2amd_encoder *e)
 
 size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet_cap, int calls_in_flight)
 {
+    if (calls_in_flight < 2) calls_in_flight = 2;
+    return ffv2amd_lanecoder_bytes_per_frame_ex(e, packet_cap, calls_in_flight, lanecoder_default_backs(calls_in_flight));
+}
+
+size_t ffv2amd_lanecoder_bytes_per_frame_ex(const ffv2amd_encoder *e, size_t packet_cap, int calls_in_flight, int backs)
+{
     if (!e) return 0;
+    if (calls_in_flight < 2) calls_in_flight = 2;
+    if (calls_in_flight > 4) calls_in_flight = 4;
+    if (backs < 1) backs = 1;
+    if (backs > calls_in_flight) backs = calls_in_flight;
     const ffv2amd_info &in = e->info;
     if (packet_cap == 0 || packet_cap > in.packet_cap_qp) packet_cap = in.packet_cap_qp;
     const size_t nb = (size_t)in.block_planes, nsb = (size_t)in.num_sb_x * in.num_sb_y;
@@ -1773,7 +1821,7 @@ size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *e, size_t packet
     const size_t shared = (size_t)lanecoder_window(maxsym) * 2 * sizeof(uint2) + packet_cap * 2 + 13 * 68 * 4 + 256;
     const size_t per_set = (nb * 4097 + 255) / 256 * 256 + packet_cap * 2
                          + nb * (sizeof(uint32_t) * FFV2_CODES_PER_BP + sizeof(FFV2SymRec) + sizeof(uint32_t) * 30) + 256;
-    return shared + (size_t)(calls_in_flight == 3 ? 3 : 2) * per_set;
+    return (size_t)backs * shared + (size_t)calls_in_flight * per_set;
 }
 
 // timing of the call that has just completed (events recorded on the back stream)
@@ -1803,6 +1851,7 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     if (nframes > lc.cap) return FFV2AMD_ERR_INVAL;
     auto &q = lc.set[lc.sub % (unsigned)lc.nsets];
     if (q.busy) return FFV2AMD_ERR_AGAIN;                        // every set is in flight
+    auto &bk = lc.bk[lc.sub % (unsigned)lc.nback];
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const ffv2amd_info &in = e->info;
@@ -1813,6 +1862,7 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
     a.codes = q.d_codes; a.status_in = q.d_status_in; a.abort_ = q.abort_; a.cnt = q.cnt; a.bits = q.bits;
     a.rowbase = q.rowbase; a.gbase = q.gbase; a.rawbase = q.rawbase; a.delta = q.delta; a.rows = q.rows; a.raw = q.raw;
     a.packets = q.packets; a.sizes = q.sizes; a.status = q.status; a.offs = q.offs;
+    a.recs = bk.recs; a.words = bk.words; a.cdfstate = bk.cdfstate; a.state = bk.state; a.fin = bk.fin;
     {   // raw header: pix_fmt & 15, then Exp-Golomb(qp) (ffv2enc.c:449-450)
         const uint32_t v = (uint32_t)qp + 1u;
         const int nbits = 31 - __builtin_clz(v);
@@ -1845,43 +1895,43 @@ int ffv2amd_lanecoder_submit(ffv2amd_encoder *e, int nframes, const void *d_fram
         HIPCHK(ffv2_launch_lc_front(a, lc.d_y, n, !count_pass, s));
     }
     HIPCHK(hipEventRecord(q.ev_front, s));
-    // back: cdf and chain window by window, then the packets.  One call's back runs at a time (its
-    // scratch exists once).  cdf of window i+1 (its own stream) beside the chain of window i; a record
+    // back: cdf and chain window by window, then the packets.  One call runs on a back at a time (its
+    // scratch exists once per back).  cdf of window i+1 (its own stream) beside the chain of window i; a record
     // buffer is refilled once the chain of two windows ago has read it.
     // (FFV2AMD_LC_SERIAL=1: everything on the back stream, cdf and chain of a window one after the other)
     static const bool serial = getenv("FFV2AMD_LC_SERIAL") && atoi(getenv("FFV2AMD_LC_SERIAL")) != 0;
-    hipStream_t sc = serial ? lc.back : lc.cdfs;
-    HIPCHK(hipStreamWaitEvent(lc.back, q.ev_front, 0));
+    hipStream_t sc = serial ? bk.back : bk.cdfs;
+    HIPCHK(hipStreamWaitEvent(bk.back, q.ev_front, 0));
     if (!serial) {
         HIPCHK(hipStreamWaitEvent(sc, q.ev_front, 0));
-        if (lc.backdone_valid) HIPCHK(hipStreamWaitEvent(sc, lc.ev_backdone, 0));
+        if (bk.backdone_valid) HIPCHK(hipStreamWaitEvent(sc, bk.ev_backdone, 0));
     }
-    HIPCHK(hipEventRecord(q.ev_back0, lc.back));
+    HIPCHK(hipEventRecord(q.ev_back0, bk.back));
     {
         int i = 0;
         for (uint32_t w0 = 0; w0 < lc.maxsym16; w0 += lc.window, i++) {
             const uint32_t w1 = lc.maxsym16 - w0 < lc.window ? lc.maxsym16 : w0 + lc.window;
             const int buf = serial ? 0 : i & 1;
-            if (!serial && i >= 2) HIPCHK(hipStreamWaitEvent(sc, lc.ev_chain[buf], 0));
+            if (!serial && i >= 2) HIPCHK(hipStreamWaitEvent(sc, bk.ev_chain[buf], 0));
             HIPCHK(ffv2_launch_lc_cdf(a, nframes, w0, w1, buf, sc));
             if (!serial) {
-                HIPCHK(hipEventRecord(lc.ev_cdf[buf], sc));
-                HIPCHK(hipStreamWaitEvent(lc.back, lc.ev_cdf[buf], 0));
+                HIPCHK(hipEventRecord(bk.ev_cdf[buf], sc));
+                HIPCHK(hipStreamWaitEvent(bk.back, bk.ev_cdf[buf], 0));
             }
-            if (i == 0) HIPCHK(hipEventRecord(q.ev_chain0, lc.back));
-            HIPCHK(ffv2_launch_lc_chain(a, nframes, w0, w1, buf, lc.back));
-            if (!serial) HIPCHK(hipEventRecord(lc.ev_chain[buf], lc.back));
+            if (i == 0) HIPCHK(hipEventRecord(q.ev_chain0, bk.back));
+            HIPCHK(ffv2_launch_lc_chain(a, nframes, w0, w1, buf, bk.back));
+            if (!serial) HIPCHK(hipEventRecord(bk.ev_chain[buf], bk.back));
         }
     }
-    HIPCHK(hipEventRecord(q.ev_chain1, lc.back));
-    HIPCHK(ffv2_launch_lc_finish(a, nframes, lc.back));
-    HIPCHK(hipEventRecord(lc.ev_backdone, lc.back));
-    lc.backdone_valid = true;
-    HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
-    HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, lc.back));
-    HIPCHK(hipMemcpyAsync(q.h_offs, q.offs, sizeof(unsigned long long) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, lc.back));
-    HIPCHK(hipMemcpyAsync(q.h_offs + (size_t)lc.cap + 1, q.gbase + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, lc.back));
-    HIPCHK(hipEventRecord(q.ev_done, lc.back));
+    HIPCHK(hipEventRecord(q.ev_chain1, bk.back));
+    HIPCHK(ffv2_launch_lc_finish(a, nframes, bk.back));
+    HIPCHK(hipEventRecord(bk.ev_backdone, bk.back));
+    bk.backdone_valid = true;
+    HIPCHK(hipMemcpyAsync(q.h_sizes, q.sizes, sizeof(uint32_t) * nframes, hipMemcpyDeviceToHost, bk.back));
+    HIPCHK(hipMemcpyAsync(q.h_status, q.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, bk.back));
+    HIPCHK(hipMemcpyAsync(q.h_offs, q.offs, sizeof(unsigned long long) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, bk.back));
+    HIPCHK(hipMemcpyAsync(q.h_offs + (size_t)lc.cap + 1, q.gbase + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, bk.back));
+    HIPCHK(hipEventRecord(q.ev_done, bk.back));
     q.nframes = nframes; q.busy = true;
     lc.sub++;
     return FFV2AMD_OK;
@@ -2267,7 +2317,7 @@ int ffv2amd_qpring_close(ffv2amd_encoder *e)
     if (r.h2d) (void)hipStreamSynchronize(r.h2d);
     (void)hipStreamSynchronize(e->stream);
     (void)ffv2amd_lanecoder_close(e);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < ffv2amd_encoder::QpRing::NBUF; i++) {
         (void)hipFree(r.d_frames[i]); (void)hipFree(r.d_c420[i]); (void)hipFree(r.d_w[i]);
         r.d_frames[i] = nullptr; r.d_c420[i] = nullptr; r.d_w[i] = nullptr; r.any_w[i] = false; r.tags[i].clear();
     }
@@ -2292,24 +2342,49 @@ int ffv2amd_qpring_close(ffv2amd_encoder *e)
     return FFV2AMD_OK;
 }
 
+static int qpring_open_with(ffv2amd_encoder *e, int qp, int frames_per_call, size_t packet_cap, int calls, int backs);
+
 int ffv2amd_qpring_open(ffv2amd_encoder *e, int qp, int frames_per_call, size_t packet_cap)
 {
     if (!e || frames_per_call < 1) return FFV2AMD_ERR_INVAL;
     if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
     if (e->qr.open) return FFV2AMD_ERR_INVAL;
     if (e->lc.cap) return FFV2AMD_ERR_INVAL;                     // the lane coder is in use by its own entry points
+    // Calls in flight, and range chains side by side.  A call lasts one frame's chain whatever it holds (0.55 s at
+    // 1080p / qp 16), the rest of its work about 0.14 ms per 1080p frame: below some 4 000 frames per call the chain
+    // is what a call waits for, and further calls' chains beside it are nearly free (1080p / qp 16, page-locked
+    // frames, same box: 512 frames per call 2.5 -> 6.9 Gpix/s, 1 024: 4.6 -> 8.8, 2 048: 7.1 -> 10.1 with four calls
+    // and four chains; 4 096 per call is at the PCIe rate with two calls and one chain).  Four calls hold five
+    // batches of frames and four sets of coder scratch: where the device cannot, fewer are tried.
+    // FFV2AMD_QPRING_CALLS (2..4) and FFV2AMD_LC_BACKS (1..calls) override.
+    const int cenv = getenv("FFV2AMD_QPRING_CALLS") ? atoi(getenv("FFV2AMD_QPRING_CALLS")) : 0;      // read per open: tests flip them
+    const int benv = getenv("FFV2AMD_LC_BACKS") ? atoi(getenv("FFV2AMD_LC_BACKS")) : 0;
+    const double mpix = (double)frames_per_call * e->info.width * e->info.height / 1e6;     // 4 096 1080p frames: 8 500
+    int calls = mpix >= 8000 ? 2 : 4;
+    if (cenv >= 2 && cenv <= 4) calls = cenv;
+    for (;;) {
+        int backs = mpix >= 8000 ? 1 : calls;
+        if (benv >= 1) backs = benv > calls ? calls : benv;
+        const int rc = qpring_open_with(e, qp, frames_per_call, packet_cap, calls, backs);
+        if (rc != FFV2AMD_ERR_NOMEM || calls == 2) return rc;
+        calls--;
+    }
+}
+
+static int qpring_open_with(ffv2amd_encoder *e, int qp, int frames_per_call, size_t packet_cap, int calls, int backs)
+{
     DeviceGuard guard(e->device);
     if (!guard.ok) return FFV2AMD_ERR_DEVICE;
     const ffv2amd_info &in = e->info;
     auto &r = e->qr;
-    int rc = ffv2amd_lanecoder_open(e, frames_per_call, packet_cap, 2);
+    int rc = ffv2amd_lanecoder_open_ex(e, frames_per_call, packet_cap, calls, backs);
     if (rc < 0) return rc;
-    r.qp = qp; r.cap = frames_per_call;
+    r.qp = qp; r.cap = frames_per_call; r.calls = calls;
     r.pcap = packet_cap ? packet_cap : in.packet_cap_qp;
 #define QK(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; } } while (0)
     QK(hipStreamCreateWithFlags(&r.h2d, hipStreamNonBlocking));
     QK(hipEventCreateWithFlags(&r.ev_batch, hipEventDisableTiming));
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i <= calls; i++) {
         QK(hipMalloc(&r.d_frames[i], in.frame_stride * (size_t)frames_per_call));
         try { r.tags[i].assign((size_t)frames_per_call, 0); r.is420[i].assign((size_t)frames_per_call, 0); }
         catch (...) { r.open = true; ffv2amd_qpring_close(e); return FFV2AMD_ERR_NOMEM; }
@@ -2352,17 +2427,18 @@ static int qpring_collect(ffv2amd_encoder *e)
     if (rc < 0) return rc;
     for (int i = 0; i < n; i++) r.done_tags[(size_t)i] = r.tags[b][(size_t)i];
     r.done_n = n; r.done_at = 0;
-    r.flight[0] = r.flight[1]; r.flight_n[0] = r.flight_n[1]; r.nflight--;
+    for (int k = 1; k < r.nflight; k++) { r.flight[k - 1] = r.flight[k]; r.flight_n[k - 1] = r.flight_n[k]; }
+    r.nflight--;
     return FFV2AMD_OK;
 }
 
-// the batch being filled -> the lane coder.  FFV2AMD_ERR_AGAIN: two calls are in flight and the one before them has
+// the batch being filled -> the lane coder.  FFV2AMD_ERR_AGAIN: `calls` calls are in flight and the one before them has
 // not been received yet (the caller has to take packets first).
 static int qpring_submit(ffv2amd_encoder *e)
 {
     auto &r = e->qr;
     if (r.count == 0) return FFV2AMD_OK;
-    if (r.nflight == 2) {
+    if (r.nflight == r.calls) {
         const int rc = qpring_collect(e);
         if (rc < 0) return rc;
     }
@@ -2388,7 +2464,7 @@ static int qpring_submit(ffv2amd_encoder *e)
     if (rc < 0) return rc;
     r.flight[r.nflight] = b; r.flight_n[r.nflight] = r.count; r.nflight++;
     // the next batch goes into the buffer no call in flight reads
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i <= r.calls; i++) {
         bool used = false;
         for (int k = 0; k < r.nflight; k++) used = used || r.flight[k] == i;
         if (!used) { r.fill = i; break; }

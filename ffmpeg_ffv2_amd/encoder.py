@@ -210,19 +210,26 @@ class FFV2Encoder:
         _lib.check(self._lib.ffv2amd_encoder_set_device_coder(self._h, 1 if on else 0), "set_device_coder")
 
     # -- qp > 0 with many frames in flight (ffv2_lanecoder.hip) --
-    def lanecoder_open(self, frames_in_flight, packet_cap=0, calls_in_flight=2):
+    def lanecoder_open(self, frames_in_flight, packet_cap=0, calls_in_flight=2, backs=None):
         """Size the device coder's HBM scratch (lanecoder_bytes_per_frame() per frame).  packet_cap: bytes
         reserved per packet (0 = info.packet_cap_qp); a frame that needs more comes back as NOSPACE.
-        calls_in_flight: 2 or 3 submitted calls before a finish is due."""
-        _lib.check(self._lib.ffv2amd_lanecoder_open(self._h, int(frames_in_flight), int(packet_cap), int(calls_in_flight)),
-                   "ffv2amd_lanecoder_open")
+        calls_in_flight: 2 to 4 submitted calls before a finish is due.  backs: range chains side by side
+        (1..calls_in_flight; None = the library's default, one)."""
+        if backs is None:
+            _lib.check(self._lib.ffv2amd_lanecoder_open(self._h, int(frames_in_flight), int(packet_cap), int(calls_in_flight)),
+                       "ffv2amd_lanecoder_open")
+        else:
+            _lib.check(self._lib.ffv2amd_lanecoder_open_ex(self._h, int(frames_in_flight), int(packet_cap), int(calls_in_flight),
+                                                           int(backs)), "ffv2amd_lanecoder_open_ex")
         self._lc_cap = int(packet_cap) or self.info.packet_cap_qp
 
     def lanecoder_close(self):
         _lib.check(self._lib.ffv2amd_lanecoder_close(self._h), "ffv2amd_lanecoder_close")
 
-    def lanecoder_bytes_per_frame(self, packet_cap=0, calls_in_flight=2):
-        return int(self._lib.ffv2amd_lanecoder_bytes_per_frame(self._h, int(packet_cap), int(calls_in_flight)))
+    def lanecoder_bytes_per_frame(self, packet_cap=0, calls_in_flight=2, backs=None):
+        if backs is None:
+            return int(self._lib.ffv2amd_lanecoder_bytes_per_frame(self._h, int(packet_cap), int(calls_in_flight)))
+        return int(self._lib.ffv2amd_lanecoder_bytes_per_frame_ex(self._h, int(packet_cap), int(calls_in_flight), int(backs)))
 
     def lanecoder_encode(self, d_frames, qp, d_W=None, packet_stride=None, as_arrays=False):
         """Up to frames_in_flight frames in HBM -> packets, the range coder running one frame per lane.

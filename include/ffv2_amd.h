@@ -251,10 +251,19 @@ int  ffv2amd_qpring_close(ffv2amd_encoder *enc);
  *                      (ffv2amd_host_alloc) for full PCIe rate.  FFV2AMD_ERR_NOSPACE (the call stays
  *                      queued) when h_cap is too small: frames * (packet_cap + 16) always suffices.
  *   lanecoder_encode : submit + finish.
+ *   lanecoder_open_ex / bytes_per_frame_ex : calls_in_flight 2..4 and `backs` 1..calls_in_flight range chains
+ *                      side by side (call n takes back n % backs; each back holds its own records, code words
+ *                      and lane state: 2 * window * 8 + 2 * packet_cap bytes per frame more).  A call lasts one
+ *                      frame's chain at least, whatever it holds; where the memory holds too few frames for
+ *                      the next call's front to fill that time (4K and larger pictures, or a few hundred
+ *                      frames per call) a second chain beside the first does.  lanecoder_open() is
+ *                      open_ex(..., backs = 1) unless the environment says FFV2AMD_LC_BACKS=n.
  * One thread drives a coder.  PARITY UNPINNED like all of qp > 0. */
 int    ffv2amd_lanecoder_open(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap, int calls_in_flight);
+int    ffv2amd_lanecoder_open_ex(ffv2amd_encoder *enc, int frames_in_flight, size_t packet_cap, int calls_in_flight, int backs);
 int    ffv2amd_lanecoder_close(ffv2amd_encoder *enc);
 size_t ffv2amd_lanecoder_bytes_per_frame(const ffv2amd_encoder *enc, size_t packet_cap, int calls_in_flight);
+size_t ffv2amd_lanecoder_bytes_per_frame_ex(const ffv2amd_encoder *enc, size_t packet_cap, int calls_in_flight, int backs);
 int    ffv2amd_lanecoder_submit(ffv2amd_encoder *enc, int nframes, const void *d_frames, int qp, const int32_t *d_W);
 int    ffv2amd_lanecoder_finish(ffv2amd_encoder *enc, uint8_t *h_packets, size_t packet_stride,
                                 uint32_t *h_sizes, int32_t *h_status);

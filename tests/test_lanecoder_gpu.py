@@ -177,6 +177,51 @@ def test_lanecoder_two_calls_in_flight(oracle):
     enc.close()
 
 
+@pytest.mark.parametrize("calls,backs", [(2, 2), (3, 2), (4, 4), (4, 1)])
+def test_lanecoder_range_chains_side_by_side(oracle, calls, backs):
+    """ffv2amd_lanecoder_open_ex: `backs` range chains at a time (call n on back n % backs, each with its own records,
+    code words and lane state).  Calls of different content and length, every set and back reused several times, small
+    windows so that every call's back is many cdf / chain launches: packets equal the synchronous path's; the
+    memory estimate grows by a back's share; arguments out of range are refused."""
+    from ffmpeg_ffv2_amd import _lib
+    W, H, fmt, P, depth, qp = 200, 130, "yuv444p10le", 3, 10, 16
+    enc = _enc(W, H, fmt, 2)
+    ncall = 9
+    batches = [np.stack([synth.noise(31 * c + i, P, H, W, depth) if (c + i) % 3 else synth.make("S1", c + i, P, H, W, depth)
+                         for i in range(1 + (c * 5) % 7)]) for c in range(ncall)]
+    dev = [enc.upload(b) for b in batches]
+    enc.lanecoder_open(7)
+    want = []
+    for c in range(ncall):
+        pk, sizes, status = enc.lanecoder_encode(dev[c], qp, as_arrays=True)
+        assert not status.any()
+        want.append([pk[i, : sizes[i]].tobytes() for i in range(len(batches[c]))])
+    assert want[3][0] == oracle.encode(batches[3][0], fmt, qp=qp)
+    one = enc.lanecoder_bytes_per_frame(0, calls, 1)
+    assert enc.lanecoder_bytes_per_frame(0, calls, backs) > one or backs == 1
+    lib = _lib.load()
+    lib.ffv2amd_debug_lanecoder_window(4096)
+    try:
+        enc.lanecoder_open(7, calls_in_flight=calls, backs=backs)
+    finally:
+        lib.ffv2amd_debug_lanecoder_window(0)
+    sub = fin = 0
+    while fin < ncall:
+        while sub < ncall and sub - fin < calls:
+            assert enc.lanecoder_submit(dev[sub], qp)
+            sub += 1
+        if sub < ncall:
+            assert not enc.lanecoder_submit(dev[sub], qp)   # every set is in flight
+        pk, sizes, status = enc.lanecoder_finish()
+        assert not status.any()
+        assert [pk[i, : sizes[i]].tobytes() for i in range(len(batches[fin]))] == want[fin], fin
+        fin += 1
+    for bad in [(2, 3), (5, 1), (1, 1), (3, -1)]:
+        with pytest.raises(_lib.FFV2Error):
+            enc.lanecoder_open(7, calls_in_flight=bad[0], backs=bad[1])
+    enc.close()
+
+
 def test_lanecoder_small_packet_cap_reports_nospace(oracle):
     """A tight packet_cap saves HBM; a frame that does not fit is refused, the others are unaffected."""
     W, H, fmt, P, depth, qp = 128, 128, "gray", 1, 8, 16

@@ -67,6 +67,38 @@ def test_qpring_packets_in_order_equal_the_oracle(oracle, fmt, P, H, W, depth, q
     enc.close()
 
 
+@pytest.mark.parametrize("calls,backs", [(2, 1), (3, 2), (4, 4)])
+def test_qpring_calls_in_flight_and_chains_side_by_side(oracle, monkeypatch, calls, backs):
+    """The ring picks four calls in flight with a range chain each for small batches; FFV2AMD_QPRING_CALLS /
+    FFV2AMD_LC_BACKS say otherwise.  Whatever they say: 23 frames in batches of 2 come back in order, equal to the
+    oracle's, and `calls` batches in flight, one finished and waiting to be received and one full are accepted
+    before a receive is due."""
+    monkeypatch.setenv("FFV2AMD_QPRING_CALLS", str(calls))
+    monkeypatch.setenv("FFV2AMD_LC_BACKS", str(backs))
+    fmt, P, H, W, depth, qp = "yuv444p", 3, 90, 140, 8, 16
+    enc = _enc(W, H, fmt)
+    n = 23
+    frames = [synth.noise(500 + i, P, H, W, depth) for i in range(n)]
+    enc.qpring_open(qp, 2)
+    got, sent = [], 0
+    while sent < n and enc.qpring_send(frames[sent], tag=sent):
+        sent += 1
+    assert sent == 2 * (calls + 2)                    # the next send needs a place: EAGAIN until a batch has been received
+    while sent < n:
+        _drain(enc, got, wait=True)
+        while sent < n and enc.qpring_send(frames[sent], tag=sent):
+            sent += 1
+    while not enc.qpring_flush():
+        _drain(enc, got, wait=True)
+    while enc.qpring_pending():
+        _drain(enc, got, wait=True)
+    assert [t for t, _ in got] == list(range(n))
+    for i, (t, pk) in enumerate(got):
+        assert pk == _want(oracle, frames[i], fmt, qp), i
+    enc.qpring_close()
+    enc.close()
+
+
 def test_qpring_yuv420_pinned_and_phantom_w(oracle):
     """4:2:0 frames (up-converted on the ring's copy stream) and 4:4:4 frames with the phantom coefficient W, page-locked
     and pageable, mixed in one ring."""

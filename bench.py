@@ -191,7 +191,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
                           "packet_bytes_frame0": int(sizes[0]), "frames_failed": int((status != 0).sum()),
                           "range_coder": "device, range chain one frame per lane, %d frames in flight" % F,
                           "coder_scratch_GB": round(F * enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight, args.backs) / 1e9, 1),
-                          "calls_in_flight": args.calls_in_flight, "range_chains_side_by_side": args.backs,
+                          "calls_in_flight": args.calls_in_flight, "range_chains_side_by_side": args.backs or 1,
                           "packet_cap": args.packet_cap or enc.info.packet_cap_qp,
                           "packets_out": "one copy per packet" if args.strided_packets else "packed, one copy"},
                "chain": dict(zip(("kernel", "ms", "back_ms", "symbols_frame0", "ns_per_symbol", "what"),
@@ -272,7 +272,7 @@ def lanecoder_bench(args, enc0, FFV2Encoder, synth, cfg, dist_cfg, barrier):
 
 def qp_host_boundary(args, enc, host_frames, F, packet0):
     """Frames in host memory -> ffv2amd_qpring_send / _receive -> packets in host memory at qp > 0: batches of
-    frames coded side by side on the device, two batches in flight.  Returns the host_boundary block."""
+    frames coded side by side on the device, two to four batches in flight.  Returns the host_boundary block."""
     enc.lanecoder_close()
     i = enc.info
     W, H = i.width, i.height
@@ -283,8 +283,8 @@ def qp_host_boundary(args, enc, host_frames, F, packet0):
     total = max(8 * per_call, min(16384, 32 * per_call))     # filling and draining the pipeline included
     nsrc = host_frames.shape[0]
     out = {"frames_per_call": per_call, "frames_sent": total, "what":
-           "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two in "
-           "flight) -> ffv2amd_qpring_receive: packets in host memory in send order; pinned: page-locked frames read in "
+           "frames in host memory -> ffv2amd_qpring_send (H2D as they arrive, a full batch = one lane coder call, two to four in "
+           "flight, their range chains side by side) -> ffv2amd_qpring_receive: packets in host memory in send order; pinned: page-locked frames read in "
            "place; pageable: rows copied by the ring's helper threads into page-locked bounce frames; pageable_registered: ordinary "
            "memory from a pool of buffers, page-locked by the ring on first sight (FFV2AMD_FRAME_REGISTER); yuv420: the literal 4:2:0 "
            "frames, up-converted on the device"}
@@ -466,8 +466,17 @@ def main():
         if args.frames_in_flight <= 0:
             if not args.packet_cap:
                 args.packet_cap = 4096 + 700 * enc.info.block_planes      # noise at qp 16 / 64 codes to 160 / 370 B per block-plane
-            per = enc.lanecoder_bytes_per_frame(args.packet_cap, args.calls_in_flight, args.backs)
-            args.frames_in_flight = max(64, min(8192, int(160e9 // per) // 64 * 64))
+            fit = lambda backs: max(64, min(8192, int(160e9 // enc.lanecoder_bytes_per_frame(
+                args.packet_cap, args.calls_in_flight, backs)) // 64 * 64))
+            args.frames_in_flight = fit(args.backs or 1)
+            if args.backs is None and args.frames_in_flight < 3800:
+                args.backs = 2
+                args.frames_in_flight = fit(2)
+        if args.backs is None:
+            # fewer frames than cover a frame's chain with the next call's front (any picture size: both grow with the
+            # pixels): a second chain beside the first, each call on its own back (4K / qp 16, same box: 8.0 -> 9.4 Gpix/s)
+            args.backs = 2 if args.frames_in_flight < 3800 else 1
+        args.backs = min(args.backs, args.calls_in_flight)
         lanecoder_bench(args, enc, FFV2Encoder, synth, (W, H, fmt, depth, P), (world, rank, local, dev, backend), barrier)
         return
     if args.qp > 0:

@@ -2350,23 +2350,35 @@ int ffv2amd_qpring_open(ffv2amd_encoder *e, int qp, int frames_per_call, size_t 
     if (qp < 1 || qp > 64) return FFV2AMD_ERR_UNSUPPORTED;
     if (e->qr.open) return FFV2AMD_ERR_INVAL;
     if (e->lc.cap) return FFV2AMD_ERR_INVAL;                     // the lane coder is in use by its own entry points
-    // Calls in flight, and range chains side by side.  A call lasts one frame's chain whatever it holds (0.55 s at
-    // 1080p / qp 16), the rest of its work about 0.14 ms per 1080p frame: below some 4 000 frames per call the chain
-    // is what a call waits for, and further calls' chains beside it are nearly free (1080p / qp 16, page-locked
-    // frames, same box: 512 frames per call 2.5 -> 6.9 Gpix/s, 1 024: 4.6 -> 8.8, 2 048: 7.1 -> 10.1 with four calls
-    // and four chains; 4 096 per call is at the PCIe rate with two calls and one chain).  Four calls hold five
-    // batches of frames and four sets of coder scratch: where the device cannot, fewer are tried.
-    // FFV2AMD_QPRING_CALLS (2..4) and FFV2AMD_LC_BACKS (1..calls) override.
+    // Calls in flight, and range chains side by side.  A call lasts one frame's chain whatever it holds (265 ns per
+    // pixel at qp 16: 0.55 s at 1080p, 1.9 s at 4K), the rest of its work about 67 ps per pixel and frame: below some
+    // 4 000 frames per call -- of any size -- the chain is what a call waits for, and further calls' chains beside it
+    // are nearly free (1080p / qp 16, page-locked frames, same box: 512 frames per call 2.5 -> 6.9 Gpix/s, 1 024:
+    // 4.6 -> 8.8, 2 048: 7.1 -> 10.1 with four calls and four chains; 4 096 per call is at the PCIe rate with two
+    // calls and one chain).  Four calls hold five batches of frames and four sets of coder scratch: where the device
+    // cannot, fewer are tried.  FFV2AMD_QPRING_CALLS (2..4) and FFV2AMD_LC_BACKS (1..calls) override.
     const int cenv = getenv("FFV2AMD_QPRING_CALLS") ? atoi(getenv("FFV2AMD_QPRING_CALLS")) : 0;      // read per open: tests flip them
     const int benv = getenv("FFV2AMD_LC_BACKS") ? atoi(getenv("FFV2AMD_LC_BACKS")) : 0;
-    const double mpix = (double)frames_per_call * e->info.width * e->info.height / 1e6;     // 4 096 1080p frames: 8 500
-    int calls = mpix >= 8000 ? 2 : 4;
+    const bool many = frames_per_call >= 3800;
+    int calls = many ? 2 : 4;
     if (cenv >= 2 && cenv <= 4) calls = cenv;
     for (;;) {
-        int backs = mpix >= 8000 ? 1 : calls;
+        int backs = many ? 1 : calls;
         if (benv >= 1) backs = benv > calls ? calls : benv;
         const int rc = qpring_open_with(e, qp, frames_per_call, packet_cap, calls, backs);
-        if (rc != FFV2AMD_ERR_NOMEM || calls == 2) return rc;
+        if (calls == 2 || (rc < 0 && rc != FFV2AMD_ERR_NOMEM)) return rc;
+        if (rc == FFV2AMD_OK) {
+            // what send allocates on first use has to fit as well: 4:2:0 chroma and W of every batch
+            const ffv2amd_info &in = e->info;
+            const size_t bps = in.depth > 8 ? 2 : 1;
+            const size_t c420 = in.planes == 3 ? 2 * align_up((size_t)((in.width + 1) >> 1) * bps, 128) * (size_t)((in.height + 1) >> 1) : 0;
+            const size_t later = (size_t)(calls + 1) * (size_t)frames_per_call * (c420 + sizeof(int32_t) * (size_t)in.block_planes)
+                               + ((size_t)512 << 20);
+            DeviceGuard guard(e->device);
+            size_t free_b = 0, total_b = 0;
+            if (!guard.ok || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= later) return rc;
+            (void)ffv2amd_qpring_close(e);
+        }
         calls--;
     }
 }

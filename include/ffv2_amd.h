@@ -188,13 +188,17 @@ int  ffv2amd_qp_pending(const ffv2amd_encoder *enc);
  * around ffv2enc.c:453; round 3).  ffv2amd_qp_send_frame above codes one frame per call with the host-thread coder
  * (tens of milliseconds per 1080p frame); this ring is the same boundary on top of the lane coder below: frames in
  * host memory are collected `frames_per_call` at a time in device memory as they arrive (H2D on the ring's own
- * stream, a 4:2:0 frame up-converted there), every full batch is one lane coder call (two in flight), and the
+ * stream, a 4:2:0 frame up-converted there), every full batch is one lane coder call (two to four in flight), and the
  * packets come back in send order, byte-identical to ffv2amd_encode_batch_to_host at that qp.
- *   qpring_open    : qp 1..64; HBM for three batches of frames plus the lane coder's scratch
- *                    (ffv2amd_lanecoder_bytes_per_frame(enc, packet_cap, 2) per frame), page-locked host memory
- *                    for one batch of packets; FFV2AMD_ERR_NOMEM if it does not fit.  Throughput grows with
- *                    frames_per_call (hundreds to thousands), and so does the delay: a packet comes back once
- *                    its whole batch is through.
+ *   qpring_open    : qp 1..64.  Below 3 800 frames per call: four calls in flight with a range chain each (a call
+ *                    lasts one frame's chain whatever it holds; four side by side cost little more than one) --
+ *                    HBM for five batches of frames plus ffv2amd_lanecoder_bytes_per_frame_ex(enc, packet_cap,
+ *                    4, 4) per frame; three or two calls where the device cannot hold that.  From 3 800 frames:
+ *                    two calls, one chain, three batches of frames.  FFV2AMD_QPRING_CALLS=2..4 and
+ *                    FFV2AMD_LC_BACKS=1..calls in the environment override.  Page-locked host memory
+ *                    for one batch of packets; FFV2AMD_ERR_NOMEM if nothing fits.  Throughput grows with
+ *                    frames_per_call (1080p / qp 16: 6.9 Gpix/s at 512, 8.8 at 1 024, 10.1 at 2 048), and so
+ *                    does the delay: a packet comes back once its whole batch is through.
  *   qpring_send    : flags FFV2AMD_FRAME_PINNED (planes page-locked and untouched until the frame's packet has
  *                    been received: the DMA engine reads them in place), FFV2AMD_FRAME_REGISTER (the same promise for
  *                    ordinary memory from a pool of long-lived buffers, page-locked here on first sight) and/or

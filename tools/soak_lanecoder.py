@@ -92,6 +92,28 @@ def run(cases=300, seed=1, max_w=400, max_h=300, max_frames=9, quiet=False, wind
                 if code == 0:
                     assert pkt == pk[i, : sizes[i]].tobytes(), (it, i, "qpring")
             enc.qpring_close()
+        if it % 3 == 1 and n >= 2:
+            # several calls in flight, a range chain each or shared (ffv2amd_lanecoder_open_ex): the frames in runs of
+            # random lengths, every run a call; packets equal the single call's above
+            calls = rnd.randint(2, 4)
+            backs = rnd.randint(1, calls)
+            enc.lanecoder_open(n, 0, calls_in_flight=calls, backs=backs)
+            cuts = sorted(rnd.sample(range(1, n), min(n - 1, rnd.randint(1, 7))))
+            runs = [(a, b) for a, b in zip([0] + cuts, cuts + [n])]
+            sub = fin = 0
+            while fin < len(runs):
+                while sub < len(runs) and sub - fin < calls:
+                    assert enc.lanecoder_submit(dev[runs[sub][0]:runs[sub][1]], qp)
+                    sub += 1
+                pk2, sizes2, status2 = enc.lanecoder_finish()
+                a, b = runs[fin]
+                for i in range(a, b):
+                    if status[i] == -28:
+                        continue
+                    assert status2[i - a] == status[i], (it, i, "calls in flight", calls, backs)
+                    if status[i] == 0:
+                        assert pk2[i - a, : sizes2[i - a]].tobytes() == pk[i, : sizes[i]].tobytes(), (it, i, "calls in flight", calls, backs)
+                fin += 1
         enc.close()
         lib.ffv2amd_debug_lanecoder_window(0)
         if it % 25 == 24 and not quiet:

@@ -2551,28 +2551,37 @@ int ffv2amd_qpring_send(ffv2amd_encoder *e, const uint8_t *const data[4], const 
             HIPCHK(hipEventSynchronize(r.ev_bounce[k]));
         }
         // rows are copied in slices, by the ring's helper threads where the picture is large enough to pay for the
-        // hand-over (FFV2AMD_GATHER_THREADS, caller included); every slice's DMA is queued as soon as it is copied
+        // hand-over (FFV2AMD_GATHER_THREADS, caller included); then one DMA per run of planes that lie back to back on
+        // both sides (a DMA per slice, queued by whichever thread had copied it, cost more in the runtime's stream lock
+        // than its early start bought: twelve calls per 6 MB frame.  The next frame's rows are copied while this
+        // frame's DMA runs, which is all the overlap the rate needs)
         uint8_t *at[4];
         at[0] = r.bounce[k];
         for (int p = 1; p < npl; p++) at[p] = at[p - 1] + pl[p - 1].pitch * (size_t)pl[p - 1].rows;
         const int per = r.pool ? 4 : 1, nsl = npl * per;
-        hipError_t up[16];
-        for (int i = 0; i < nsl; i++) up[i] = hipSuccess;
         const std::function<void(int)> slice = [&](int i) {
             const int p = i / per, q = i % per;
             const int y0 = (int)((long long)pl[p].rows * q / per), y1 = (int)((long long)pl[p].rows * (q + 1) / per);
-            if (y1 <= y0) return;
+            if (pl[p].ls == (ptrdiff_t)pl[p].pitch && y1 > y0) {
+                memcpy(at[p] + (size_t)y0 * pl[p].pitch, pl[p].src + (ptrdiff_t)y0 * pl[p].ls,
+                       pl[p].pitch * (size_t)(y1 - y0 - 1) + pl[p].row_bytes);
+                return;
+            }
             for (int y = y0; y < y1; y++)
                 memcpy(at[p] + (size_t)y * pl[p].pitch, pl[p].src + (ptrdiff_t)y * pl[p].ls, pl[p].row_bytes);
-            up[i] = hipMemcpyAsync(pl[p].dst + (size_t)y0 * pl[p].pitch, at[p] + (size_t)y0 * pl[p].pitch,
-                                   pl[p].pitch * (size_t)(y1 - y0 - 1) + pl[p].row_bytes, hipMemcpyHostToDevice, sh);
         };
         if (r.pool) {
             try { r.pool->run(nsl, slice); } catch (...) { return FFV2AMD_ERR_NOMEM; }
         } else {
             for (int i = 0; i < nsl; i++) slice(i);
         }
-        for (int i = 0; i < nsl; i++) HIPCHK(up[i]);
+        for (int p = 0; p < npl; ) {
+            int p1 = p + 1;
+            while (p1 < npl && pl[p1].dst == pl[p1 - 1].dst + pl[p1 - 1].pitch * (size_t)pl[p1 - 1].rows) p1++;   // at[] is back to back by construction
+            const size_t bytes = (size_t)(at[p1 - 1] - at[p]) + pl[p1 - 1].pitch * (size_t)(pl[p1 - 1].rows - 1) + pl[p1 - 1].row_bytes;
+            HIPCHK(hipMemcpyAsync(pl[p].dst, at[p], bytes, hipMemcpyHostToDevice, sh));
+            p = p1;
+        }
         HIPCHK(hipEventRecord(r.ev_bounce[k], sh));
     }
     r.is420[b][(size_t)r.count] = is420 ? 1 : 0;                 // up-converted when the batch leaves (qpring_submit)

@@ -990,7 +990,11 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     CK(hipMalloc(&e->d_bitoff, sizeof(uint32_t) * g.nblk * (size_t)max_batch));
     CK(hipMalloc(&e->d_status, sizeof(int32_t) * (size_t)max_batch));
     CK(hipMalloc(&e->d_err, sizeof(int32_t) * 2 * (size_t)max_batch));
-    CK(hipMemset(e->d_err, 0, sizeof(int32_t) * 2 * (size_t)max_batch));
+    // hipMemset() of device memory does not wait for the fill (it runs on the null stream, which none of this library's
+    // non-blocking streams synchronise with): a fill still in flight when the first E-stage has cleared or read the
+    // flags would land on top of them.  On the encoder's stream, and waited for.
+    CK(hipMemsetAsync(e->d_err, 0, sizeof(int32_t) * 2 * (size_t)max_batch, e->stream));
+    CK(hipStreamSynchronize(e->stream));
     CK(hipMalloc(&e->d_frame, in.frame_stride));
     CK(hipMalloc(&e->d_pkt, in.packet_cap));
     CK(hipMalloc(&e->d_meta, 16));
@@ -2806,7 +2810,7 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
         RK(hipMalloc(&r.d_frame, in.frame_stride));
         RK(hipMalloc(&r.d_pkt, in.packet_cap));
         RK(hipMalloc(&r.d_meta, 16));
-        RK(hipMemset(r.d_meta, 0, 16));                          // [2]: the T-stage's error flag, zero between calls
+        RK(hipMemsetAsync(r.d_meta, 0, 16, e->ring_d2h));        // [2]: the T-stage's error flag, zero between calls (waited for below)
         RK(hipMalloc(&r.d_codes, sizeof(uint32_t) * FFV2_CODES_PER_BP * nb));
         RK(hipMalloc(&r.d_bitcnt, sizeof(uint32_t) * nb));
         RK(hipMalloc(&r.d_w, sizeof(int32_t) * nb));
@@ -2817,6 +2821,11 @@ int ffv2amd_ring_open(ffv2amd_encoder *e, int depth)
         RK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));
         RK(hipEventCreateWithFlags(&r.ev_meta, hipEventDisableTiming));
     }
+    // the fills above have to be through before the first frame: a plain hipMemset() of device memory returns before
+    // the fill has run (null stream; the ring's streams are non-blocking), and one that landed after the first
+    // E-stage had written {size, status} there made ring_receive see a packet of 0 bytes (once in some 5 000 first
+    // frames of a ring, and only once 16 hardware queues had taken the accidental ordering away)
+    RK(hipStreamSynchronize(e->ring_d2h));
 #undef RK
     e->ring_head = e->ring_count = 0;
     // helpers for pageable frames: a 4K plane is 16 MB of row copies, PCIe moves 55 GB/s, one host

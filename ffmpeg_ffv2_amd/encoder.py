@@ -91,6 +91,15 @@ class FFV2Encoder:
         import torch
         return torch.from_numpy(self.pack_frames(frames)).to("cuda:%d" % self.device)
 
+    @staticmethod
+    def _producer_done(*tensors):
+        """The entry points without a stream argument run on the library's own (non-blocking) streams, which wait for
+        nobody: whatever torch still has queued that writes these tensors has to be through first."""
+        import torch
+        for t in tensors:
+            if t is not None:
+                torch.cuda.current_stream(t.device).synchronize()
+
     def tstage(self, d_frames, want_coef=True, want_energy=True):
         """d_frames: torch uint8 (F, frame_stride) on this device -> (coef, energy) torch tensors."""
         import torch
@@ -164,6 +173,7 @@ class FFV2Encoder:
         pk = np.empty((F, cap), np.uint8)
         sizes = np.zeros(F, np.uint32)
         status = np.zeros(F, np.int32)
+        self._producer_done(d_frames, d_W)
         _lib.check(self._lib.ffv2amd_encode_batch_to_host(
             self._h, F, d_frames.data_ptr(), qp, d_W.data_ptr() if d_W is not None else None,
             pk.ctypes.data_as(C.c_void_p), cap, sizes.ctypes.data_as(C.c_void_p),
@@ -237,6 +247,7 @@ class FFV2Encoder:
         (the array is reused by the next call with the same shape)."""
         if getattr(self, "_lc_pending", None):
             raise _lib.FFV2Error(-22, "lanecoder_encode with submitted calls in flight")
+        self._producer_done(d_frames, d_W)
         _lib.check(self._lib.ffv2amd_lanecoder_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
                                                       d_W.data_ptr() if d_W is not None else None), "ffv2amd_lanecoder_submit")
         self._lc_pending = [(d_frames, d_W)]
@@ -252,6 +263,7 @@ class FFV2Encoder:
     def lanecoder_submit(self, d_frames, qp, d_W=None):
         """Asynchronous half of lanecoder_encode.  False when calls_in_flight calls are already in flight.  The
         frames must stay alive and untouched until the matching lanecoder_finish()."""
+        self._producer_done(d_frames, d_W)
         r = self._lib.ffv2amd_lanecoder_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
                                                d_W.data_ptr() if d_W is not None else None)
         if r == -11:
@@ -314,6 +326,7 @@ class FFV2Encoder:
 
     def qp_submit(self, d_frames, qp, d_W=None):
         """GPU half of a qp > 0 batch (asynchronous).  False when two batches are already in flight."""
+        self._producer_done(d_frames, d_W)
         r = self._lib.ffv2amd_qp_submit(self._h, d_frames.shape[0], d_frames.data_ptr(), qp,
                                         d_W.data_ptr() if d_W is not None else None)
         if r == -11:

@@ -240,7 +240,10 @@ int  ffv2amd_qpring_close(ffv2amd_encoder *enc);
  *                      whose packet would not fit comes back as FFV2AMD_ERR_NOSPACE (noise at
  *                      qp 16 / 64 codes to 160 / 370 bytes per block-plane).
  *   lanecoder_submit : up to that many device-resident frames (layout of ffv2amd_info), qp 1..64.
- *                      Asynchronous; the frames (and W) stay untouched until the call's finish.
+ *                      Asynchronous; the frames (and W) stay untouched until the call's finish, and they are
+ *                      COMPLETE when the call is made: the coder's streams are its own and wait for no stream
+ *                      of the caller's (the same holds for ffv2amd_qp_submit and ffv2amd_encode_batch_to_host,
+ *                      which take no stream argument either).
  *                      calls_in_flight (2, or 3; 0 = 2) calls may be in flight (FFV2AMD_ERR_AGAIN
  *                      for one more; each holds its own copy of the smaller buffers): the transform,
  *                      PVQ search and symbol bookkeeping of call n+1 then run beside the range

@@ -995,6 +995,7 @@ int ffv2amd_encoder_create(ffv2amd_encoder **out, int width, int height, int pix
     // flags would land on top of them.  On the encoder's stream, and waited for.
     CK(hipMemsetAsync(e->d_err, 0, sizeof(int32_t) * 2 * (size_t)max_batch, e->stream));
     CK(hipStreamSynchronize(e->stream));
+    CK(hipStreamSynchronize(nullptr));                           // the tables above went over the null stream: through, whatever a plain copy promises
     CK(hipMalloc(&e->d_frame, in.frame_stride));
     CK(hipMalloc(&e->d_pkt, in.packet_cap));
     CK(hipMalloc(&e->d_meta, 16));
@@ -1687,6 +1688,7 @@ static int lanecoder_alloc(ffv2amd_encoder *e, int frames, size_t pcap, int nset
         for (int k = 0; k < 4; k++) cdf[k] += 128;
     }
     HIPCHK(hipMemcpy(lc.d_split, split.data(), sizeof(uint2) * nsb, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(nullptr));                       // null stream: the coder's streams do not wait for it
     const uint32_t hs = (uint32_t)in.pix_fmt >> 4;
     auto q15 = [](uint32_t k) { return (32768u * k + 6u) / 13u; };
     a.header = make_uint2((hs ? q15(hs) : 0u) | (q15(hs + 1) << 16), 32768u);

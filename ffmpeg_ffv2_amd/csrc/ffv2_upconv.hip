@@ -349,7 +349,8 @@ FFV2Upconv *ffv2_upconv_create(int w, int h, int depth)
     ok = ok && hipMemcpy(u->d_hf, hx.coef.data(), hx.coef.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(u->d_vf, vy.coef.data(), vy.coef.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(u->d_hp, hx.pos.data(), hx.pos.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(u->d_vp, vy.pos.data(), vy.pos.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+         hipMemcpy(u->d_vp, vy.pos.data(), vy.pos.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipStreamSynchronize(nullptr) == hipSuccess;      // null stream: the callers' streams do not wait for it
     if (!ok) { ffv2_upconv_destroy(u); return nullptr; }
     return u;
 }

@@ -396,7 +396,7 @@ def main():
                          "the front's buffers)")
     ap.add_argument("--backs", type=int, default=None, choices=(1, 2, 3, 4),
                     help="with --qp on the device coder: range chains side by side (ffv2amd_lanecoder_open_ex; at most "
-                         "--calls-in-flight; default: the library's)")
+                         "--calls-in-flight; default: 2 where fewer than 3 800 frames are in flight, else 1)")
     ap.add_argument("--packet-cap", type=int, default=0,
                     help="with --frames-in-flight: bytes of HBM reserved per packet (0 = the encoder's bound for any qp)")
     ap.add_argument("--qp", type=int, default=0,

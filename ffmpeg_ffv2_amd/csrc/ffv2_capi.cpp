@@ -875,7 +875,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
         if (q.h_codes) (void)hipHostFree(q.h_codes);
         if (q.h_status) (void)hipHostFree(q.h_status);
         if (q.ev) (void)hipEventDestroy(q.ev);
-        for (auto ev : q.ev_frame) (void)hipEventDestroy(ev);
+        for (auto ev : q.ev_frame) if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(q.d_pre); (void)hipFree(q.d_raw); (void)hipFree(q.d_pk); (void)hipFree(q.d_pk_sizes); (void)hipFree(q.d_pk_status);
         if (q.h_pk_sizes) (void)hipHostFree(q.h_pk_sizes);
         if (q.h_pk_status) (void)hipHostFree(q.h_pk_status);
@@ -903,6 +903,7 @@ void ffv2amd_encoder_destroy(ffv2amd_encoder *e)
     for (int i = 0; i < 2; i++) { if (e->evT[i]) (void)hipEventDestroy(e->evT[i]); if (e->evE[i]) (void)hipEventDestroy(e->evE[i]); }
     (void)hipFree(e->d_codes2); (void)hipFree(e->d_bitoff2); (void)hipFree(e->d_status2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    (void)hipGetLastError();              // nothing refused above may surface in another encoder's launch check
     delete e;
 }
 
